@@ -1,0 +1,30 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+@pytest.fixture(scope="session")
+def weights_blob():
+    def _get(short="dari_tult"):
+        return np.fromfile(os.path.join(GOLDEN, f"weights_{short}.bin"), dtype=np.float32)
+    return _get

@@ -1,0 +1,75 @@
+"""DSP half of the oracle: PARITY UNPINNED by the reference (torchaudio absent,
+no reference tests).  Double-entry check: the torch restatement
+(oracle/dsp_ref.py) against the independent float64 numpy implementation
+(oracle/dsp_np64.py), plus size-independent properties."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import dsp_np64, dsp_ref, pipeline_ref
+
+PARAMS = [pipeline_ref.PARAMS_S, pipeline_ref.PARAMS_R1, pipeline_ref.PARAMS_R2]
+
+
+@pytest.mark.parametrize("p", PARAMS, ids=["S", "R1", "R2"])
+def test_frame_gives_three_columns_and_matches_np64(p):
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(3, p.n_fft, generator=g)
+    s = dsp_ref.spectrogram(x, p.n_fft, p.hop)
+    assert s.shape == (3, p.n_stft, 3)
+    s64 = dsp_np64.stft(x.numpy(), p.n_fft, p.hop)
+    assert np.abs(s.numpy() - s64).max() <= 2e-4 * np.abs(s64).max()
+
+
+@pytest.mark.parametrize("p", PARAMS, ids=["S", "R1", "R2"])
+def test_filterbank_matches_np64_and_is_full_rank(p):
+    fb = dsp_ref.melscale_fbanks(p.n_stft, p.n_mels, p.sample_rate)
+    fb64 = dsp_np64.mel_fbanks(p.n_stft, p.n_mels, p.sample_rate)
+    assert fb.shape == (p.n_stft, p.n_mels)
+    assert np.abs(fb.numpy() - fb64).max() <= 5e-5
+    assert np.linalg.matrix_rank(fb64) == p.n_mels
+    assert (fb.sum(0) > 0).all()
+
+
+@pytest.mark.parametrize("p", PARAMS, ids=["S", "R1", "R2"])
+def test_inverse_mel_lstsq_is_min_norm_pinv(p):
+    fb = dsp_ref.melscale_fbanks(p.n_stft, p.n_mels, p.sample_rate)
+    g = torch.Generator().manual_seed(2)
+    mel = torch.rand(4, p.n_mels, 3, generator=g) * 20
+    a = dsp_ref.inverse_mel_scale(mel, fb).numpy()
+    b = dsp_np64.inverse_mel_scale(mel.numpy(), fb.numpy())
+    assert np.abs(a - b).max() <= 2e-4
+
+
+@pytest.mark.parametrize("p", [pipeline_ref.PARAMS_S, pipeline_ref.PARAMS_R1], ids=["S", "R1"])
+def test_istft_inverts_stft(p):
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, p.n_fft, generator=g)
+    y = dsp_ref.inverse_spectrogram(dsp_ref.spectrogram(x, p.n_fft, p.hop), p.n_fft, p.hop)
+    assert y.shape == x.shape and (y - x).abs().max() <= 1e-4
+    y64 = dsp_np64.istft(dsp_np64.stft(x.numpy(), p.n_fft, p.hop), p.n_fft, p.hop)
+    assert np.abs(y64 - x.numpy()).max() <= 1e-10
+
+
+def test_griffinlim_matches_np64_with_shared_init():
+    p = pipeline_ref.PARAMS_S
+    g = torch.Generator().manual_seed(4)
+    x = 0.1 * torch.randn(2, p.n_fft, generator=g)
+    mag = dsp_ref.spectrogram(x, p.n_fft, p.hop).abs()
+    init = torch.rand(mag.shape, dtype=torch.complex64, generator=g)
+    y = dsp_ref.griffinlim(mag, p.n_fft, p.hop, init_angles=init).numpy()
+    y64 = dsp_np64.griffinlim(mag.numpy(), p.n_fft, p.hop, init.numpy())
+    assert y.shape == (2, p.n_fft)
+    rms = np.sqrt(np.mean((y - y64) ** 2))
+    assert rms <= 1e-3            # north_star waveform tolerance; fp32 vs fp64 is ~1e-5
+
+
+def test_golden_dsp_fixture_is_reproduced():
+    """The committed dsp_S.npz freezes the restatement (and documents the
+    silent-frame branch app3.py:182-186)."""
+    g = load_golden("dsp_S.npz")
+    p = pipeline_ref.PARAMS_S
+    mi, peak = pipeline_ref.analysis(torch.from_numpy(g["frames"]), p, torch.from_numpy(g["fb"]))
+    assert np.abs(mi.numpy() - g["model_input"]).max() <= 1e-4
+    assert peak[4] == 1.0 and peak[5] == 1.0
