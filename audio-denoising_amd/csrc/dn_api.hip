@@ -1,0 +1,546 @@
+// dn_api.hip -- the C ABI of include/dn_denoise.h: handle construction (host-side packing of
+// the reference's tensors into kernel-friendly layouts) and launch wrappers.  No kernel code here.
+#include <math.h>
+#include <string.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "dn_internal.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define DN_HIP(call)                                                                                     \
+    do {                                                                                                 \
+        hipError_t e_ = (call);                                                                          \
+        if (e_ != hipSuccess) return fail(DN_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(DN_ERR_HIP, std::string(what) + " launch: " + hipGetErrorString(e));
+    return DN_OK;
+}
+
+// One device allocation holding several arrays, 256-byte aligned slots.
+struct DevArena {
+    char* base = nullptr;
+    size_t size = 0;
+    std::vector<char> host;
+    size_t add(const void* src, size_t bytes) {
+        size_t off = (host.size() + 255) & ~size_t(255);
+        host.resize(off + bytes);
+        memcpy(host.data() + off, src, bytes);
+        return off;
+    }
+    hipError_t upload() {
+        size = host.size();
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&base), size ? size : 256);
+        if (e != hipSuccess) return e;
+        e = hipMemcpy(base, host.data(), size, hipMemcpyHostToDevice);
+        host.clear();
+        host.shrink_to_fit();
+        return e;
+    }
+    template <typename T>
+    const T* ptr(size_t off) const { return reinterpret_cast<const T*>(base + off); }
+    void release() {
+        if (base) (void)hipFree(base);
+        base = nullptr;
+    }
+};
+
+// ------------------------------------------------------------------ model
+// state_dict order, SURVEY.md Appendix A.4 (offsets in floats)
+struct StateLayout {
+    size_t dw[4], db[4], off_in, gw, gb, off_rs, uw[4], ub[4], off_out, total;
+    StateLayout() {
+        size_t o = 0;
+        const int dco[4] = {17, 17, 17, 51}, dci[4] = {7, 23, 23, 23};
+        for (int l = 0; l < 4; ++l) { dw[l] = o; o += (size_t)dco[l] * dci[l] * 3; db[l] = o; o += dco[l]; }
+        off_in = o; o += 6;
+        gw = o; o += 51 * 23 * 3; gb = o; o += 51;
+        off_rs = o; o += 6;
+        const int uci[4] = {23, 40, 40, 40}, uco[4] = {17, 17, 17, 1};
+        for (int l = 0; l < 4; ++l) { uw[l] = o; o += (size_t)uci[l] * uco[l] * 3; ub[l] = o; o += uco[l]; }
+        off_out = o; o += 6;
+        total = o;
+    }
+};
+
+// torch.linspace(0, 1, n) in fp32 (symmetric two-sided formula of the CPU kernel)
+std::vector<float> linspace01(int n) {
+    std::vector<float> v(n);
+    if (n == 1) { v[0] = 0.0f; return v; }
+    const float step = 1.0f / (float)(n - 1);
+    const int half = n / 2;
+    for (int i = 0; i < n; ++i) v[i] = i < half ? 0.0f + step * (float)i : 1.0f - step * (float)(n - 1 - i);
+    return v;
+}
+
+// GaussianSmearing table S[g][l], gruunet2.py:54-68 on linspace(0,1,L)
+std::vector<float> smear_table(const float* offset, int L) {
+    const float diff = offset[1] - offset[0];
+    const double coeff = -0.5 / ((double)diff * (double)diff);
+    const float cf = (float)coeff;
+    std::vector<float> pos = linspace01(L), s((size_t)dn::kGauss * L);
+    for (int g = 0; g < dn::kGauss; ++g)
+        for (int l = 0; l < L; ++l) {
+            const float d = pos[l] - offset[g];
+            s[(size_t)g * L + l] = expf(cf * (d * d));
+        }
+    return s;
+}
+
+struct BiasSet {
+    DevArena arena;
+    dn::CellDev view;
+};
+
+}  // namespace
+
+struct dn_model {
+    dn_model_cfg cfg;
+    std::vector<float> w;      // the caller's flat state_dict
+    DevArena packed;           // data-channel weights, [c][k][o]
+    size_t off_down[4], off_gh, off_up[4];
+    std::mutex mu;
+    std::map<int, BiasSet*> bias;   // per number of compressed bins C
+};
+
+struct dn_dsp {
+    dn_dsp_cfg cfg;
+    DevArena arena;
+    dn::DspDev view;
+    std::vector<float> fb, pinv, window;   // host copies [K][M], [K][M], [N]
+};
+
+namespace {
+
+int build_bias(dn_model* m, int C, BiasSet** out) {
+    std::lock_guard<std::mutex> lock(m->mu);
+    auto it = m->bias.find(C);
+    if (it != m->bias.end()) { *out = it->second; return DN_OK; }
+    const StateLayout sl;
+    const float* W = m->w.data();
+    const int F = 16 * C;
+    BiasSet* bs = new BiasSet();
+    size_t o_down[4], o_gh, o_up[4];
+    // encoder levels: Lin = F >> l, Lout = Lin/2, stride 2, left pad 1
+    for (int l = 0; l < 4; ++l) {
+        const int cd = l == 0 ? 1 : 17, ct = cd + 6, co = l == 3 ? 51 : 17;
+        const int lin = F >> l, lout = lin / 2;
+        std::vector<float> S = smear_table(W + sl.off_in, lin), bt((size_t)co * lout);
+        for (int o = 0; o < co; ++o)
+            for (int j = 0; j < lout; ++j) {
+                double acc = W[sl.db[l] + o];
+                for (int g = 0; g < 6; ++g)
+                    for (int k = 0; k < 3; ++k) {
+                        const int p = 2 * j - 1 + k;
+                        if (p >= 0 && p < lin) acc += (double)W[sl.dw[l] + ((size_t)o * ct + cd + g) * 3 + k] * S[(size_t)g * lin + p];
+                    }
+                bt[(size_t)o * lout + j] = (float)acc;
+            }
+        o_down[l] = bs->arena.add(bt.data(), bt.size() * sizeof(float));
+    }
+    {   // hidden gates: stride 1, pad 1 on both sides, length C
+        std::vector<float> S = smear_table(W + sl.off_rs, C), bt((size_t)51 * C);
+        for (int o = 0; o < 51; ++o)
+            for (int p = 0; p < C; ++p) {
+                double acc = W[sl.gb + o];
+                for (int g = 0; g < 6; ++g)
+                    for (int k = 0; k < 3; ++k) {
+                        const int q = p - 1 + k;
+                        if (q >= 0 && q < C) acc += (double)W[sl.gw + ((size_t)o * 23 + 17 + g) * 3 + k] * S[(size_t)g * C + q];
+                    }
+                bt[(size_t)o * C + p] = (float)acc;
+            }
+        o_gh = bs->arena.add(bt.data(), bt.size() * sizeof(float));
+    }
+    // decoder levels: Lin = C << l, Lout = 2 Lin; output j = 2 i - 1 + k
+    for (int l = 0; l < 4; ++l) {
+        const int cd = l == 0 ? 17 : 34, co = l == 3 ? 1 : 17;
+        const int lin = C << l, lout = 2 * lin;
+        std::vector<float> S = smear_table(W + sl.off_out, lin), bt((size_t)co * lout);
+        for (int o = 0; o < co; ++o)
+            for (int j = 0; j < lout; ++j) {
+                double acc = W[sl.ub[l] + o];
+                for (int g = 0; g < 6; ++g)
+                    for (int k = 0; k < 3; ++k) {
+                        const int num = j + 1 - k;          // 2 i
+                        if (num < 0 || (num & 1)) continue;
+                        const int i = num >> 1;
+                        if (i < lin) acc += (double)W[sl.uw[l] + ((size_t)(cd + g) * co + o) * 3 + k] * S[(size_t)g * lin + i];
+                    }
+                bt[(size_t)o * lout + j] = (float)acc;
+            }
+        o_up[l] = bs->arena.add(bt.data(), bt.size() * sizeof(float));
+    }
+    hipError_t e = bs->arena.upload();
+    if (e != hipSuccess) { bs->arena.release(); delete bs; return fail(DN_ERR_HIP, std::string("bias table upload: ") + hipGetErrorString(e)); }
+    for (int l = 0; l < 4; ++l) {
+        bs->view.w_down[l] = m->packed.ptr<float>(m->off_down[l]);
+        bs->view.w_up[l] = m->packed.ptr<float>(m->off_up[l]);
+        bs->view.bt_down[l] = bs->arena.ptr<float>(o_down[l]);
+        bs->view.bt_up[l] = bs->arena.ptr<float>(o_up[l]);
+    }
+    bs->view.w_gh = m->packed.ptr<float>(m->off_gh);
+    bs->view.bt_gh = bs->arena.ptr<float>(o_gh);
+    m->bias[C] = bs;
+    *out = bs;
+    return DN_OK;
+}
+
+// Cholesky solve of the SPD system G X = R in double; G is n x n (row-major), R is n x m. In place.
+bool chol_solve(std::vector<double>& G, std::vector<double>& R, int n, int m) {
+    for (int j = 0; j < n; ++j) {
+        double d = G[(size_t)j * n + j];
+        for (int k = 0; k < j; ++k) d -= G[(size_t)j * n + k] * G[(size_t)j * n + k];
+        if (!(d > 0.0)) return false;
+        d = sqrt(d);
+        G[(size_t)j * n + j] = d;
+        for (int i = j + 1; i < n; ++i) {
+            double s = G[(size_t)i * n + j];
+            for (int k = 0; k < j; ++k) s -= G[(size_t)i * n + k] * G[(size_t)j * n + k];
+            G[(size_t)i * n + j] = s / d;
+        }
+    }
+    for (int c = 0; c < m; ++c) {
+        for (int i = 0; i < n; ++i) {           // L y = r
+            double s = R[(size_t)i * m + c];
+            for (int k = 0; k < i; ++k) s -= G[(size_t)i * n + k] * R[(size_t)k * m + c];
+            R[(size_t)i * m + c] = s / G[(size_t)i * n + i];
+        }
+        for (int i = n - 1; i >= 0; --i) {      // L^T x = y
+            double s = R[(size_t)i * m + c];
+            for (int k = i + 1; k < n; ++k) s -= G[(size_t)k * n + i] * R[(size_t)k * m + c];
+            R[(size_t)i * m + c] = s / G[(size_t)i * n + i];
+        }
+    }
+    return true;
+}
+
+hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+}  // namespace
+
+extern "C" {
+
+const char* dn_last_error(void) { return g_err.c_str(); }
+int dn_abi_version(void) { return DN_ABI_VERSION; }
+
+int dn_model_create(const float* weights, size_t n_floats, const dn_model_cfg* cfg, dn_model** out) {
+    if (!weights || !cfg || !out) return fail(DN_ERR_INVALID, "dn_model_create: null argument");
+    const StateLayout sl;
+    if (cfg->in_size != 1) return fail(DN_ERR_INVALID, "in_size must be 1 (gruunet2.py:257)");
+    if (cfg->n_levels != 4 || cfg->hidden_size != 17 || cfg->kernel_size != 3 || cfg->stride != 2 ||
+        cfg->padding != 1 || cfg->num_gaussians != 6)
+        return fail(DN_ERR_UNSUPPORTED, "kernels are built for 4 levels, hidden 17, k3 s2 p1, 6 gaussians");
+    if (cfg->num_compressed_bins < 1 || cfg->num_compressed_bins > dn::kMaxC)
+        return fail(DN_ERR_UNSUPPORTED, "num_compressed_bins must be in 1.." + std::to_string(dn::kMaxC));
+    if (n_floats != sl.total) return fail(DN_ERR_INVALID, "expected " + std::to_string(sl.total) + " weight floats, got " + std::to_string(n_floats));
+    dn_model* m = new dn_model();
+    m->cfg = *cfg;
+    m->w.assign(weights, weights + n_floats);
+    const float* W = m->w.data();
+    for (int l = 0; l < 4; ++l) {   // Conv1d weight (Cout, Ct, 3) -> [c][k][o], data channels c < Cd
+        const int cd = l == 0 ? 1 : 17, ct = cd + 6, co = l == 3 ? 51 : 17;
+        std::vector<float> p((size_t)cd * 3 * co);
+        for (int c = 0; c < cd; ++c)
+            for (int k = 0; k < 3; ++k)
+                for (int o = 0; o < co; ++o) p[((size_t)c * 3 + k) * co + o] = W[sl.dw[l] + ((size_t)o * ct + c) * 3 + k];
+        m->off_down[l] = m->packed.add(p.data(), p.size() * sizeof(float));
+    }
+    {
+        std::vector<float> p((size_t)17 * 3 * 51);
+        for (int c = 0; c < 17; ++c)
+            for (int k = 0; k < 3; ++k)
+                for (int o = 0; o < 51; ++o) p[((size_t)c * 3 + k) * 51 + o] = W[sl.gw + ((size_t)o * 23 + c) * 3 + k];
+        m->off_gh = m->packed.add(p.data(), p.size() * sizeof(float));
+    }
+    for (int l = 0; l < 4; ++l) {   // ConvTranspose1d weight (Ct, Cout, 3) -> [c][k][o]
+        const int cd = l == 0 ? 17 : 34, co = l == 3 ? 1 : 17;
+        std::vector<float> p((size_t)cd * 3 * co);
+        for (int c = 0; c < cd; ++c)
+            for (int k = 0; k < 3; ++k)
+                for (int o = 0; o < co; ++o) p[((size_t)c * 3 + k) * co + o] = W[sl.uw[l] + ((size_t)c * co + o) * 3 + k];
+        m->off_up[l] = m->packed.add(p.data(), p.size() * sizeof(float));
+    }
+    hipError_t e = m->packed.upload();
+    if (e != hipSuccess) { m->packed.release(); delete m; return fail(DN_ERR_HIP, std::string("weight upload: ") + hipGetErrorString(e)); }
+    BiasSet* bs = nullptr;
+    int rc = build_bias(m, cfg->num_compressed_bins, &bs);
+    if (rc != DN_OK) { m->packed.release(); delete m; return rc; }
+    *out = m;
+    return DN_OK;
+}
+
+void dn_model_destroy(dn_model* m) {
+    if (!m) return;
+    for (auto& kv : m->bias) { kv.second->arena.release(); delete kv.second; }
+    m->packed.release();
+    delete m;
+}
+
+int dn_cell_forward(const dn_model* m, const float* x, const float* hx_in, float* out, float* hx_out, int32_t B,
+                    int32_t T, int32_t F, int32_t C, void* stream) {
+    if (!m || !x || !out || !hx_out) return fail(DN_ERR_INVALID, "dn_cell_forward: null argument");
+    if (B < 0 || T < 0) return fail(DN_ERR_INVALID, "dn_cell_forward: negative size");
+    if (C < 1 || C > dn::kMaxC) return fail(DN_ERR_UNSUPPORTED, "compressed bins C must be in 1.." + std::to_string(dn::kMaxC));
+    if (F != 16 * C)
+        return fail(DN_ERR_INVALID, "input has " + std::to_string(F) + " bins, which compress to " + std::to_string(F / 16) +
+                                        ", but hx has " + std::to_string(C) + " compressed bins (need F == 16*C)");
+    if (B == 0) return DN_OK;
+    BiasSet* bs = nullptr;
+    int rc = build_bias(const_cast<dn_model*>(m), C, &bs);
+    if (rc != DN_OK) return rc;
+    dn::launch_cell(bs->view, x, hx_in, out, hx_out, B, T, C, as_stream(stream));
+    return check_launch("cell_kernel");
+}
+
+int dn_dsp_create(const dn_dsp_cfg* cfg, const float* fb_in, const float* pinv_in, const float* window_in, dn_dsp** out) {
+    if (!cfg || !out) return fail(DN_ERR_INVALID, "dn_dsp_create: null argument");
+    if (cfg->n_fft != dn::kNfft || cfg->hop != cfg->n_fft / 2)
+        return fail(DN_ERR_UNSUPPORTED, "kernels are built for n_fft = 1024, hop = 512 (got n_fft " + std::to_string(cfg->n_fft) +
+                                            ", hop " + std::to_string(cfg->hop) + ")");
+    const int N = cfg->n_fft, K = N / 2 + 1, M = cfg->n_mels;
+    if (M < 0 || M > 128) return fail(DN_ERR_UNSUPPORTED, "n_mels must be in 0..128");
+    if (M > 0 && cfg->sample_rate <= 0) return fail(DN_ERR_INVALID, "sample_rate must be positive");
+    dn_dsp* d = new dn_dsp();
+    d->cfg = *cfg;
+    const double PI = 3.14159265358979323846;
+    // window (torch.hann_window periodic) and istft envelope reciprocal
+    d->window.resize(N);
+    for (int n = 0; n < N; ++n) d->window[n] = window_in ? window_in[n] : (float)(0.5 - 0.5 * cos(2.0 * PI * n / N));
+    std::vector<float> inv_env(N);
+    for (int i = 0; i < N; ++i) {
+        const float a = d->window[i], b = d->window[(i + N / 2) & (N - 1)];
+        const float env = a * a + b * b;
+        if (!(env > 1e-11f)) { delete d; return fail(DN_ERR_INVALID, "window overlap-add envelope is ~0 (torch.istft would raise)"); }
+        inv_env[i] = (float)(1.0 / (double)env);
+    }
+    std::vector<float> tw512(2 * 512), tw1024(2 * 513);
+    for (int k = 0; k < 512; ++k) { tw512[2 * k] = (float)cos(2.0 * PI * k / 512); tw512[2 * k + 1] = (float)-sin(2.0 * PI * k / 512); }
+    for (int k = 0; k <= 512; ++k) { tw1024[2 * k] = (float)cos(2.0 * PI * k / 1024); tw1024[2 * k + 1] = (float)-sin(2.0 * PI * k / 1024); }
+    size_t o_tw512 = d->arena.add(tw512.data(), tw512.size() * 4), o_tw1024 = d->arena.add(tw1024.data(), tw1024.size() * 4);
+    size_t o_win = d->arena.add(d->window.data(), N * 4), o_env = d->arena.add(inv_env.data(), N * 4);
+    size_t o_ms = 0, o_ml = 0, o_mw = 0, o_pinv = 0;
+    int maxlen = 0;
+    const int pstride = (K + 7) & ~7;
+    if (M > 0) {
+        d->fb.resize((size_t)K * M);
+        if (fb_in) memcpy(d->fb.data(), fb_in, d->fb.size() * 4);
+        else {   // HTK triangles, f_min 0, f_max sr//2, norm None
+            const double f_hi = (double)(cfg->sample_rate / 2);
+            const double mmax = 2595.0 * log10(1.0 + f_hi / 700.0);
+            std::vector<double> fp(M + 2);
+            for (int i = 0; i < M + 2; ++i) fp[i] = 700.0 * (pow(10.0, (mmax * i / (M + 1)) / 2595.0) - 1.0);
+            for (int k = 0; k < K; ++k) {
+                const double f = f_hi * k / (K - 1);
+                for (int mm = 0; mm < M; ++mm) {
+                    const double up = (f - fp[mm]) / (fp[mm + 1] - fp[mm]), down = (fp[mm + 2] - f) / (fp[mm + 2] - fp[mm + 1]);
+                    d->fb[(size_t)k * M + mm] = (float)fmax(0.0, fmin(up, down));
+                }
+            }
+        }
+        // band structure: [first nonzero bin, last nonzero bin] of each filter
+        std::vector<int> start(M), len(M);
+        for (int mm = 0; mm < M; ++mm) {
+            int lo = K, hi = -1;
+            for (int k = 0; k < K; ++k)
+                if (d->fb[(size_t)k * M + mm] != 0.0f) { lo = k < lo ? k : lo; hi = k; }
+            start[mm] = hi < 0 ? 0 : lo;
+            len[mm] = hi < 0 ? 0 : hi - lo + 1;
+            maxlen = len[mm] > maxlen ? len[mm] : maxlen;
+        }
+        std::vector<float> mw((size_t)(maxlen ? maxlen : 1) * M, 0.0f);
+        for (int mm = 0; mm < M; ++mm)
+            for (int i = 0; i < len[mm]; ++i) mw[(size_t)i * M + mm] = d->fb[(size_t)(start[mm] + i) * M + mm];
+        // pseudo-inverse of fb^T: fb (fb^T fb)^-1, the minimum-norm least-squares operator (Appendix B.4)
+        d->pinv.resize((size_t)K * M);
+        if (pinv_in) memcpy(d->pinv.data(), pinv_in, d->pinv.size() * 4);
+        else {
+            std::vector<double> G((size_t)M * M, 0.0), R((size_t)M * K);
+            for (int a = 0; a < M; ++a)
+                for (int b = 0; b <= a; ++b) {
+                    double s = 0.0;
+                    for (int k = 0; k < K; ++k) s += (double)d->fb[(size_t)k * M + a] * d->fb[(size_t)k * M + b];
+                    G[(size_t)a * M + b] = G[(size_t)b * M + a] = s;
+                }
+            for (int a = 0; a < M; ++a)
+                for (int k = 0; k < K; ++k) R[(size_t)a * K + k] = d->fb[(size_t)k * M + a];   // fb^T
+            if (!chol_solve(G, R, M, K)) { delete d; return fail(DN_ERR_INVALID, "mel filterbank is rank deficient; pass pinv explicitly"); }
+            for (int k = 0; k < K; ++k)
+                for (int a = 0; a < M; ++a) d->pinv[(size_t)k * M + a] = (float)R[(size_t)a * K + k];
+        }
+        std::vector<float> pt((size_t)M * pstride, 0.0f);
+        for (int k = 0; k < K; ++k)
+            for (int a = 0; a < M; ++a) pt[(size_t)a * pstride + k] = d->pinv[(size_t)k * M + a];
+        o_ms = d->arena.add(start.data(), M * 4);
+        o_ml = d->arena.add(len.data(), M * 4);
+        o_mw = d->arena.add(mw.data(), mw.size() * 4);
+        o_pinv = d->arena.add(pt.data(), pt.size() * 4);
+    }
+    hipError_t e = d->arena.upload();
+    if (e != hipSuccess) { d->arena.release(); delete d; return fail(DN_ERR_HIP, std::string("plan upload: ") + hipGetErrorString(e)); }
+    dn::DspDev& v = d->view;
+    v.tw512 = d->arena.ptr<float2>(o_tw512);
+    v.tw1024 = d->arena.ptr<float2>(o_tw1024);
+    v.window = d->arena.ptr<float>(o_win);
+    v.inv_env = d->arena.ptr<float>(o_env);
+    v.n_mels = M;
+    v.mel_maxlen = maxlen;
+    v.pinv_stride = pstride;
+    v.mel_start = M ? d->arena.ptr<int>(o_ms) : nullptr;
+    v.mel_len = M ? d->arena.ptr<int>(o_ml) : nullptr;
+    v.mel_w = M ? d->arena.ptr<float>(o_mw) : nullptr;
+    v.pinv_t = M ? d->arena.ptr<float>(o_pinv) : nullptr;
+    *out = d;
+    return DN_OK;
+}
+
+void dn_dsp_destroy(dn_dsp* d) {
+    if (!d) return;
+    d->arena.release();
+    delete d;
+}
+
+int dn_dsp_get_tables(const dn_dsp* d, float* fb, float* pinv, float* window) {
+    if (!d) return fail(DN_ERR_INVALID, "dn_dsp_get_tables: null plan");
+    if (fb && !d->fb.empty()) memcpy(fb, d->fb.data(), d->fb.size() * 4);
+    if (pinv && !d->pinv.empty()) memcpy(pinv, d->pinv.data(), d->pinv.size() * 4);
+    if (window) memcpy(window, d->window.data(), d->window.size() * 4);
+    return DN_OK;
+}
+
+int dn_stft(const dn_dsp* d, const float* frames, float* spec, int32_t B, uint32_t flags, void* stream) {
+    if (!d || !frames || !spec) return fail(DN_ERR_INVALID, "dn_stft: null argument");
+    if (B < 0) return fail(DN_ERR_INVALID, "dn_stft: negative batch");
+    if (B == 0) return DN_OK;
+    dn::launch_stft(d->view, frames, spec, nullptr, nullptr, B, flags, as_stream(stream));
+    return check_launch("stft_kernel");
+}
+
+int dn_stft_mel_log1p(const dn_dsp* d, const float* frames, float* mel, float* peak, int32_t B, uint32_t flags, void* stream) {
+    if (!d || !frames || !mel) return fail(DN_ERR_INVALID, "dn_stft_mel_log1p: null argument");
+    if (d->cfg.n_mels <= 0) return fail(DN_ERR_INVALID, "plan was created without mel stages");
+    if (B < 0) return fail(DN_ERR_INVALID, "dn_stft_mel_log1p: negative batch");
+    if (B == 0) return DN_OK;
+    dn::launch_stft(d->view, frames, nullptr, mel, peak, B, flags, as_stream(stream));
+    return check_launch("stft_kernel");
+}
+
+int dn_mel_scale(const dn_dsp* d, const float* mag, float* mel, int32_t B, int32_t T, void* stream) {
+    if (!d || !mag || !mel) return fail(DN_ERR_INVALID, "dn_mel_scale: null argument");
+    if (d->cfg.n_mels <= 0) return fail(DN_ERR_INVALID, "plan was created without mel stages");
+    if (B < 0 || T < 0) return fail(DN_ERR_INVALID, "dn_mel_scale: negative size");
+    if ((int64_t)B * T == 0) return DN_OK;
+    dn::launch_mel(d->view, mag, mel, B * T, as_stream(stream));
+    return check_launch("mel_kernel");
+}
+
+int dn_invmel(const dn_dsp* d, const float* mel_mag, float* lin, int32_t B, int32_t T, void* stream) {
+    if (!d || !mel_mag || !lin) return fail(DN_ERR_INVALID, "dn_invmel: null argument");
+    if (d->cfg.n_mels <= 0) return fail(DN_ERR_INVALID, "plan was created without mel stages");
+    if (B < 0 || T < 0) return fail(DN_ERR_INVALID, "dn_invmel: negative size");
+    if ((int64_t)B * T == 0) return DN_OK;
+    dn::launch_invmel(d->view, mel_mag, nullptr, lin, B * T, as_stream(stream));
+    return check_launch("invmel_kernel");
+}
+
+int dn_residual_invmel(const dn_dsp* d, const float* x, const float* diff, float* lin, int32_t B, int32_t T, void* stream) {
+    if (!d || !x || !diff || !lin) return fail(DN_ERR_INVALID, "dn_residual_invmel: null argument");
+    if (d->cfg.n_mels <= 0) return fail(DN_ERR_INVALID, "plan was created without mel stages");
+    if (B < 0 || T < 0) return fail(DN_ERR_INVALID, "dn_residual_invmel: negative size");
+    if ((int64_t)B * T == 0) return DN_OK;
+    dn::launch_invmel(d->view, x, diff, lin, B * T, as_stream(stream));
+    return check_launch("invmel_kernel");
+}
+
+int dn_griffinlim(const dn_dsp* d, const float* mag, const float* init_angles, uint64_t seed, uint64_t stream_id0,
+                  const float* scale, float* wave, int32_t B, int32_t n_iter, float momentum, void* stream) {
+    if (!d || !mag || !wave) return fail(DN_ERR_INVALID, "dn_griffinlim: null argument");
+    if (B < 0 || n_iter < 0) return fail(DN_ERR_INVALID, "dn_griffinlim: negative size");
+    if (!(momentum >= 0.0f && momentum < 1.0f)) return fail(DN_ERR_INVALID, "momentum must be in [0, 1)");
+    if (B == 0) return DN_OK;
+    dn::launch_griffinlim(d->view, mag, init_angles, seed, stream_id0, scale, wave, B, n_iter, momentum, as_stream(stream));
+    return check_launch("griffinlim_kernel");
+}
+
+int dn_istft(const dn_dsp* d, const float* spec, float* wave, int32_t B, void* stream) {
+    if (!d || !spec || !wave) return fail(DN_ERR_INVALID, "dn_istft: null argument");
+    if (B < 0) return fail(DN_ERR_INVALID, "dn_istft: negative batch");
+    if (B == 0) return DN_OK;
+    dn::launch_griffinlim(d->view, nullptr, spec, 0, 0, nullptr, wave, B, 0, 0.0f, as_stream(stream));
+    return check_launch("griffinlim_kernel(istft)");
+}
+
+static size_t frame_scratch_bytes(const dn_dsp* d, int32_t B) {
+    const size_t M = (size_t)d->cfg.n_mels, K = (size_t)d->cfg.n_fft / 2 + 1;
+    return ((size_t)B * (6 * M + 3 * K + 1) * sizeof(float) + 255) & ~size_t(255);
+}
+
+size_t dn_workspace_bytes(const dn_dsp* d, int32_t B) {
+    if (!d || B <= 0) return 0;
+    // per-hop scratch (mel in, mel residual, linear magnitude, peak) + one denoised frame for dn_stream_step
+    return frame_scratch_bytes(d, B) + (((size_t)B * d->cfg.n_fft * sizeof(float) + 255) & ~size_t(255));
+}
+
+int dn_process_frame(const dn_model* m, const dn_dsp* d, const float* frames, float* hx, float* out, float* mel_residual_out,
+                     const float* init_angles, uint64_t seed, uint64_t stream_id0, int32_t n_iter, float momentum,
+                     void* workspace, int32_t B, void* stream) {
+    if (!m || !d || !frames || !hx || !out || !workspace) return fail(DN_ERR_INVALID, "dn_process_frame: null argument");
+    if (d->cfg.n_mels <= 0 || d->cfg.n_mels % 16) return fail(DN_ERR_INVALID, "n_mels must be a positive multiple of 16");
+    if (B < 0 || n_iter < 0) return fail(DN_ERR_INVALID, "dn_process_frame: negative size");
+    if (!(momentum >= 0.0f && momentum < 1.0f)) return fail(DN_ERR_INVALID, "momentum must be in [0, 1)");
+    if (B == 0) return DN_OK;
+    const int M = d->cfg.n_mels, K = d->cfg.n_fft / 2 + 1, C = M / 16;
+    if (C > dn::kMaxC) return fail(DN_ERR_UNSUPPORTED, "n_mels/16 exceeds the cell kernel's limit");
+    float* ws = static_cast<float*>(workspace);
+    float* mel_in = ws;
+    float* diff = mel_residual_out ? mel_residual_out : mel_in + (size_t)B * 3 * M;
+    float* lin = mel_in + (size_t)B * 6 * M;
+    float* peak = lin + (size_t)B * 3 * K;
+    BiasSet* bs = nullptr;
+    int rc = build_bias(const_cast<dn_model*>(m), C, &bs);
+    if (rc != DN_OK) return rc;
+    hipStream_t st = as_stream(stream);
+    dn::launch_stft(d->view, frames, nullptr, mel_in, peak, B, DN_PEAK_NORMALIZE | DN_PRE_WINDOW, st);      // P1-P6
+    if ((rc = check_launch("stft_kernel")) != DN_OK) return rc;
+    dn::launch_cell(bs->view, mel_in, hx, diff, hx, B, 3, C, st);                                          // P7
+    if ((rc = check_launch("cell_kernel")) != DN_OK) return rc;
+    dn::launch_invmel(d->view, mel_in, diff, lin, B * 3, st);                                              // P8-P10
+    if ((rc = check_launch("invmel_kernel")) != DN_OK) return rc;
+    dn::launch_griffinlim(d->view, lin, init_angles, seed, stream_id0, peak, out, B, n_iter, momentum, st); // P11 + `* peak`
+    return check_launch("griffinlim_kernel");
+}
+
+int dn_stream_step(const dn_model* m, const dn_dsp* d, const float* hop_in, float* ring, float* ola, float* hx, float* hop_out,
+                   const float* init_angles, uint64_t seed, uint64_t stream_id0, int32_t n_iter, float momentum, void* workspace,
+                   int32_t B, void* stream) {
+    if (!hop_in || !ring || !ola || !hop_out || !workspace) return fail(DN_ERR_INVALID, "dn_stream_step: null argument");
+    if (B < 0) return fail(DN_ERR_INVALID, "dn_stream_step: negative batch");
+    if (B == 0) return DN_OK;
+    hipStream_t st = as_stream(stream);
+    dn::launch_stream_shift(hop_in, ring, B, st);
+    int rc = check_launch("stream_shift_kernel");
+    if (rc != DN_OK) return rc;
+    // the denoised frame lands at the head of the workspace tail (after the process_frame scratch)
+    if (!d) return fail(DN_ERR_INVALID, "dn_stream_step: null plan");
+    float* y = reinterpret_cast<float*>(static_cast<char*>(workspace) + frame_scratch_bytes(d, B));
+    rc = dn_process_frame(m, d, ring, hx, y, nullptr, init_angles, seed, stream_id0, n_iter, momentum, workspace, B, stream);
+    if (rc != DN_OK) return rc;
+    dn::launch_stream_ola(y, ola, hop_out, B, st);
+    return check_launch("stream_ola_kernel");
+}
+
+}  // extern "C"

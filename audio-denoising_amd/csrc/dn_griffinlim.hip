@@ -1,0 +1,151 @@
+// dn_griffinlim.hip -- 32-iteration fast Griffin-Lim on a 3-column spectrogram, one persistent
+// workgroup per stream.  Replaces torchaudio.transforms.GriffinLim as called at app3.py:149-153,213
+// (algorithm: SURVEY.md Appendix B.5) and, with n_iter = 0, torch.istft (server.py:174,216).
+//
+// The reference runs 32 x {istft, stft, phase update} as ~65 separate passes over
+// (B,513,3) complex tensors.  Here a workgroup of three wavefronts (one per STFT column) keeps
+// the whole problem on chip for all iterations:
+//   registers : per lane 8 bins (+Nyquist) of magnitude, current phase estimate and previous
+//               rebuilt spectrum, the FFT twiddles and the folded window constants
+//   LDS       : one 576-entry complex exchange tile per wave, and a ping-pong pair of
+//               overlap-add lines (the 2*n_fft padded signal collapses to two n_fft lines
+//               because only the centre n_fft samples survive the istft trim)
+//   HBM       : magnitudes in (3*513 floats), waveform out (1024 floats).  That is all.
+// One __syncthreads per iteration (overlap-add hand-off between the three columns); every
+// FFT-internal exchange is wave-private.
+#include "dn_internal.hpp"
+#include "dn_wavefft.hpp"
+
+namespace dn {
+
+constexpr int kGlThreads = 192;
+
+// Philox4x32-10 counter-based generator (Salmon et al. 2011).
+__device__ __forceinline__ void philox4x32(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+        c[0] = n0; c[1] = (uint32_t)p1; c[2] = n2; c[3] = (uint32_t)p0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+// real, imag ~ U[0,1) independently (torch.rand(dtype=complex64) semantics), keyed by
+// (seed, global stream id, column, bin) so sharding streams over GPUs does not change results.
+__device__ __forceinline__ float2 rand_angle(uint64_t seed, uint64_t sid, int col, int bin) {
+    uint32_t c[4] = {(uint32_t)bin, (uint32_t)col, (uint32_t)sid, (uint32_t)(sid >> 32)};
+    philox4x32(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    return make_float2((float)(c[0] >> 8) * (1.0f / 16777216.0f), (float)(c[1] >> 8) * (1.0f / 16777216.0f));
+}
+
+__global__ __launch_bounds__(kGlThreads) void griffinlim_kernel(DspDev d, const float* __restrict__ mag,
+                                                                const float2* __restrict__ init, uint64_t seed,
+                                                                uint64_t sid0, const float* __restrict__ scale,
+                                                                float* __restrict__ wave, int n_iter, float mom) {
+    __shared__ float2 tile[3][kFftTile];
+    __shared__ float ybuf[2][2][kNR];     // [ping-pong][0: centre column, 1: halves of columns 0 and 2][n]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const size_t b = blockIdx.x;
+    float2* mytile = tile[w];
+
+    FftTwiddles tw;
+    load_twiddles(tw, d.tw512, lane);
+
+    // lane constants: bin twiddles, synthesis window / 512, analysis window * 1/envelope and
+    // the source sample indices of this column in the rebuilt signal s[0..1024):
+    //   column 0: n < 512 -> s[512-n] (reflection), else s[n-512]
+    //   column 1: s[n]
+    //   column 2: n < 512 -> s[n+512], else s[1534-n] (reflection)
+    float2 wk[8], wsyn[8], cw[8];
+    int src0[8], src1[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int m = lane + 64 * t;
+        wk[t] = d.tw1024[m];
+        const float2 ww = reinterpret_cast<const float2*>(d.window)[m];
+        wsyn[t] = make_float2(ww.x * (1.0f / 512.0f), ww.y * (1.0f / 512.0f));
+        const int n0 = 2 * m, n1 = n0 + 1;
+        int i0, i1;
+        if (w == 1) { i0 = n0; i1 = n1; }
+        else if (w == 0) { i0 = n0 < 512 ? 512 - n0 : n0 - 512; i1 = n1 < 512 ? 512 - n1 : n1 - 512; }
+        else { i0 = n0 < 512 ? n0 + 512 : 1534 - n0; i1 = n1 < 512 ? n1 + 512 : 1534 - n1; }
+        src0[t] = i0; src1[t] = i1;
+        cw[t] = make_float2(ww.x * d.inv_env[i0], ww.y * d.inv_env[i1]);
+    }
+
+    // per-lane state: 8 bins k = lane + 64 t, plus the Nyquist bin (meaningful in lane 0)
+    float mg[8], mgn;
+    float2 ang[8], tprev[8];
+    float angn_re, tprevn = 0.0f;
+    {
+        const size_t row = (b * 3 + w) * kBins;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int k = lane + 64 * t;
+            mg[t] = mag != nullptr ? mag[row + k] : 1.0f;
+            ang[t] = init != nullptr ? init[row + k] : rand_angle(seed, sid0 + b, w, k);
+            tprev[t] = make_float2(0.0f, 0.0f);
+        }
+        mgn = mag != nullptr ? mag[row + 512] : 1.0f;
+        angn_re = init != nullptr ? init[row + 512].x : rand_angle(seed, sid0 + b, w, 512).x;
+    }
+
+    float2 v[8];
+    for (int it = 0;; ++it) {
+        // ---- istft of angles * magnitude: irfft per column, synthesis window, overlap-add lines
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] = make_float2(ang[t].x * mg[t], ang[t].y * mg[t]);
+        irfft1024(v, angn_re * mgn, tw, wk, mytile, mytile, lane);
+        float* y1 = ybuf[it & 1][0];
+        float* yo = ybuf[it & 1][1];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int n0 = 2 * (lane + 64 * t);
+            const float2 y = make_float2(v[t].x * wsyn[t].x, v[t].y * wsyn[t].y);
+            if (w == 1) *reinterpret_cast<float2*>(y1 + n0) = y;
+            else if (w == 0) { if (t >= 4) *reinterpret_cast<float2*>(yo + n0 - 512) = y; }
+            else { if (t < 4) *reinterpret_cast<float2*>(yo + n0 + 512) = y; }
+        }
+        __syncthreads();
+        if (it == n_iter) {
+            // final istft: divide by the window envelope, trim, scale (app3.py:217 `* peak`)
+            const float sc = scale != nullptr ? scale[b] : 1.0f;
+            for (int n = tid; n < kNR; n += kGlThreads)
+                wave[b * kNR + n] = (y1[n] + yo[n]) * d.inv_env[n] * sc;
+            break;
+        }
+        // ---- stft of the rebuilt signal (centre, reflect): this wave's column, analysis window
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+            v[t] = make_float2((y1[src0[t]] + yo[src0[t]]) * cw[t].x, (y1[src1[t]] + yo[src1[t]]) * cw[t].y);
+        const float rn = rfft1024(v, tw, wk, mytile, mytile, lane);
+        // ---- phase update with momentum: a = rebuilt - m*tprev; angles = a / (|a| + 1e-16)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const float ax = v[t].x - mom * tprev[t].x, ay = v[t].y - mom * tprev[t].y;
+            tprev[t] = v[t];
+            const float inv = 1.0f / (sqrtf(fmaf(ax, ax, ay * ay)) + 1e-16f);
+            ang[t] = make_float2(ax * inv, ay * inv);
+        }
+        {
+            const float an = rn - mom * tprevn;
+            tprevn = rn;
+            angn_re = an / (fabsf(an) + 1e-16f);
+        }
+    }
+}
+
+void launch_griffinlim(const DspDev& d, const float* mag, const float* init, uint64_t seed, uint64_t sid0,
+                       const float* scale, float* wave, int B, int n_iter, float momentum, hipStream_t st) {
+    const float mom = momentum / (1.0f + momentum);
+    hipLaunchKernelGGL(griffinlim_kernel, dim3(B), dim3(kGlThreads), 0, st, d, mag,
+                       reinterpret_cast<const float2*>(init), seed, sid0, scale, wave, n_iter, mom);
+}
+
+}  // namespace dn

@@ -1,0 +1,29 @@
+// dn_internal.hpp -- launcher prototypes shared between dn_api.hip and the kernel files.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/dn_denoise.h"
+#include "dn_plan.hpp"
+
+namespace dn {
+
+constexpr int kNfft = 1024;     // n_fft the FFT kernels are built for (hop = 512)
+constexpr int kHidden = 17;      // H
+constexpr int kGates = 51;       // 3H
+constexpr int kGauss = 6;        // G
+constexpr int kCellChunk = 3;    // time steps whose encoder/decoder run batched (= columns per hop)
+constexpr int kMaxC = 5;         // compressed bins supported by the cell kernel (51*C gate lanes <= 256; F <= 80)
+
+void launch_stft(const DspDev& d, const float* frames, float* spec, float* mel, float* peak, int B, uint32_t flags,
+                 hipStream_t st);
+void launch_mel(const DspDev& d, const float* mag, float* mel, int rows, hipStream_t st);
+void launch_invmel(const DspDev& d, const float* x, const float* diff, float* lin, int rows, hipStream_t st);
+void launch_griffinlim(const DspDev& d, const float* mag, const float* init, uint64_t seed, uint64_t sid0,
+                       const float* scale, float* wave, int B, int n_iter, float momentum, hipStream_t st);
+void launch_cell(const CellDev& c, const float* x, const float* hx_in, float* out, float* hx_out, int B, int T,
+                 int C, hipStream_t st);
+void launch_stream_shift(const float* hop_in, float* ring, int B, hipStream_t st);
+void launch_stream_ola(const float* y, float* ola, float* hop_out, int B, hipStream_t st);
+
+}  // namespace dn

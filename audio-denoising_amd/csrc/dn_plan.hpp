@@ -1,0 +1,35 @@
+// dn_plan.hpp -- device-side views of the immutable handles (passed to kernels by value).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dn {
+
+// STFT / mel / inverse-mel / Griffin-Lim constants, all resident in HBM (L2-hot: ~0.4 MB total).
+struct DspDev {
+    const float2* tw512;    // [512]  exp(-2 pi i k/512)
+    const float2* tw1024;   // [513]  exp(-2 pi i k/1024)
+    const float* window;    // [1024] analysis == synthesis window (periodic Hann by default)
+    const float* inv_env;   // [1024] 1 / (w[i]^2 + w[(i+512)&1023]^2): istft envelope over the kept region
+    // banded mel filterbank: filter m covers bins [mel_start[m], mel_start[m]+mel_len[m])
+    const int* mel_start;   // [M]
+    const int* mel_len;     // [M]
+    const float* mel_w;     // [mel_maxlen][M]  weight of the i-th bin of filter m
+    int mel_maxlen;
+    int n_mels;
+    const float* pinv_t;    // [M][kPinvStride]  pseudo-inverse of fb^T, transposed, row-padded
+    int pinv_stride;
+};
+
+// Packed GRUUNet2 weights (data channels only; the position-code channels are folded into
+// the per-position bias tables `bt_*`, which depend on the number of compressed bins C).
+struct CellDev {
+    const float* w_down[4];  // [Cd][3][Cout]   Cd = 1,17,17,17   Cout = 17,17,17,51
+    const float* w_gh;       // [17][3][51]
+    const float* w_up[4];    // [Cd][3][Cout]   Cd = 17,34,34,34  Cout = 17,17,17,1
+    const float* bt_down[4]; // [Cout][Lout]    Lout = 8C,4C,2C,C
+    const float* bt_gh;      // [51][C]
+    const float* bt_up[4];   // [Cout][Lout]    Lout = 2C,4C,8C,16C
+};
+
+}  // namespace dn

@@ -1,0 +1,165 @@
+/*
+ * dn_denoise.h -- C ABI of the MI355X-native per-hop speech-denoising path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no torch types.
+ * Every buffer argument marked [dev] is a DEVICE pointer owned by the caller
+ * (e.g. torch.Tensor.data_ptr() of a contiguous fp32 tensor on the GPU); the
+ * library never frees or retains it beyond the call.  Arguments marked
+ * [host] are host pointers read during the call only.  All kernels are
+ * enqueued on the HIP stream passed in (`stream`, a hipStream_t cast to
+ * void*; NULL = the null stream); no call synchronises the device.
+ * Handles are immutable after creation and may be shared by threads.
+ *
+ * Reference interfaces replaced (file:line in belacks/audio-denoising):
+ *   dn_model_create / dn_cell_forward   gruunet2.py:246-306  GRUUNet2.__init__/forward
+ *                                       (called at app3.py:112-116, 200-201; server.py:151,212)
+ *   dn_dsp_create                       app3.py:135-155  construction of the torchaudio
+ *                                       Spectrogram/MelScale/InverseMelScale/GriffinLim + Hann window
+ *   dn_stft                             app3.py:191      Spectrogram(power=None)(x)
+ *   dn_stft_mel_log1p                   app3.py:179-195  peak-normalise, Hann, STFT, |.|, MelScale, log1p, transpose
+ *   dn_mel_scale                        app3.py:193      MelScale(mag)
+ *   dn_invmel / dn_residual_invmel      app3.py:203-211  leaky_relu(in-out), expm1, clamp, InverseMelScale, clamp
+ *   dn_griffinlim                       app3.py:213-217  GriffinLim(power=1)(lin) (* peak)
+ *   dn_istft                            server.py:174,216 InverseSpectrogram
+ *   dn_process_frame                    app3.py:178-217  the whole per-hop loop body for B streams
+ *   dn_stream_step                      app3.py:178-226  the same plus ring buffer / overlap-add state (P12)
+ *
+ * Memory layouts (row-major, fp32; "complex" = interleaved re,im float pairs):
+ *   frames      [B][n_fft]
+ *   spec        [B][T][K] complex      K = n_fft/2+1, T = 3 columns per frame.  The reference's
+ *                                      (B,K,T) tensors are the transpose(-1,-2) VIEW of this buffer.
+ *   mel / x     [B][T][M]              exactly the (B,T,F) tensor GRUUNet2.forward takes
+ *   hx          [B][17][C]             C = M/16
+ *   mag         [B][T][K]
+ *   wave        [B][n_fft]
+ *
+ * Return value: 0 on success, negative dn_status on failure; the message of
+ * the last failure on the calling thread is returned by dn_last_error().
+ */
+#ifndef DN_DENOISE_H
+#define DN_DENOISE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DN_ABI_VERSION 1
+
+typedef enum dn_status {
+    DN_OK = 0,
+    DN_ERR_INVALID = -1,      /* bad argument / shape mismatch */
+    DN_ERR_UNSUPPORTED = -2,  /* configuration outside what the kernels are built for */
+    DN_ERR_HIP = -3,          /* HIP runtime failure (message has hipGetErrorString) */
+    DN_ERR_NOMEM = -4
+} dn_status;
+
+typedef struct dn_model dn_model; /* GRUUNet2 weights, packed and resident on one device */
+typedef struct dn_dsp dn_dsp;     /* STFT/mel/inverse-mel/Griffin-Lim plan, resident on one device */
+
+/* Constructor arguments of gruunet2.GRUUNet2 (gruunet2.py:248-255).  The kernels are built for
+ * the architecture of every GRUUNet2 checkpoint in the reference: 4 levels, hidden 17, k3 s2 p1,
+ * 6 gaussians; anything else returns DN_ERR_UNSUPPORTED. */
+typedef struct dn_model_cfg {
+    int32_t num_compressed_bins; /* C; default hx is zeros(B,17,C) */
+    int32_t in_size;             /* must be 1 (gruunet2.py:257) */
+    int32_t n_levels;            /* 4 */
+    int32_t hidden_size;         /* 17 (all levels equal) */
+    int32_t kernel_size;         /* 3 */
+    int32_t stride;              /* 2 */
+    int32_t padding;             /* 1 */
+    int32_t num_gaussians;       /* 6 */
+} dn_model_cfg;
+
+#define DN_MODEL_N_FLOATS 15337  /* state_dict order, SURVEY.md Appendix A.4 */
+
+/* weights [host]: the reference state_dict flattened in its own key order (15,337 fp32).
+ * The handle lives on the current HIP device. */
+int dn_model_create(const float* weights, size_t n_floats, const dn_model_cfg* cfg, dn_model** out);
+void dn_model_destroy(dn_model* m);
+
+/* GRUUNet2.forward for B independent streams, T sequential steps.
+ *   x [dev][B][T][F], hx_in [dev][B][17][C] (NULL = zeros), out [dev][B][T][F], hx_out [dev][B][17][C].
+ * F must equal 16*C (else DN_ERR_INVALID, mirroring the reference's shape error).  hx_in is not
+ * modified (gruunet2.py:240 builds a new tensor); hx_out may alias hx_in. */
+int dn_cell_forward(const dn_model* m, const float* x, const float* hx_in, float* out, float* hx_out,
+                    int32_t B, int32_t T, int32_t F, int32_t C, void* stream);
+
+typedef struct dn_dsp_cfg {
+    int32_t sample_rate;
+    int32_t n_fft;   /* 1024 (hop = n_fft/2, win_length = n_fft) */
+    int32_t hop;
+    int32_t n_mels;  /* 0 = no mel stages */
+} dn_dsp_cfg;
+
+/* fb [host][K][n_mels]: mel filterbank as MelScale.fb (NULL = HTK triangles computed natively, f_min 0,
+ * f_max sr//2, norm None).  pinv [host][K][n_mels]: pseudo-inverse of fb^T used by the inverse-mel GEMM
+ * (NULL = computed natively in double precision from fb).  window [host][n_fft] (NULL = periodic Hann). */
+int dn_dsp_create(const dn_dsp_cfg* cfg, const float* fb, const float* pinv, const float* window, dn_dsp** out);
+void dn_dsp_destroy(dn_dsp* d);
+/* Copies of the plan's host-side tables, for inspection/tests: fb and pinv are [K][n_mels]. */
+int dn_dsp_get_tables(const dn_dsp* d, float* fb, float* pinv, float* window);
+
+/* flags for the analysis entry points */
+#define DN_PEAK_NORMALIZE 1u /* P1: x /= max|x| when that is > 1e-6 (app3.py:181-186) */
+#define DN_PRE_WINDOW 2u     /* P2: multiply by the window before the STFT windows again (app3.py:188) */
+
+/* Spectrogram(power=None): frames [dev][B][n_fft] -> spec [dev][B][3][K] complex. */
+int dn_stft(const dn_dsp* d, const float* frames, float* spec, int32_t B, uint32_t flags, void* stream);
+
+/* P1,P2,P4,P5,P6 fused: frames -> mel [dev][B][3][M] = log1p(MelScale(|STFT|)), peak [dev][B]
+ * (peak may be NULL; it is 1 where normalisation was skipped). */
+int dn_stft_mel_log1p(const dn_dsp* d, const float* frames, float* mel, float* peak, int32_t B,
+                      uint32_t flags, void* stream);
+
+/* MelScale alone: mag [dev][B][T][K] -> mel [dev][B][T][M] (no log). */
+int dn_mel_scale(const dn_dsp* d, const float* mag, float* mel, int32_t B, int32_t T, void* stream);
+
+/* InverseMelScale: mel_mag [dev][B][T][M] -> lin [dev][B][T][K] = relu(pinv(fb^T) @ mel). */
+int dn_invmel(const dn_dsp* d, const float* mel_mag, float* lin, int32_t B, int32_t T, void* stream);
+
+/* P8,P9,P10 fused: lin = relu(pinv @ clamp(expm1(leaky_relu(x - diff, 0.2)), 0)).
+ * x, diff [dev][B][T][M]; lin [dev][B][T][K]. */
+int dn_residual_invmel(const dn_dsp* d, const float* x, const float* diff, float* lin, int32_t B, int32_t T,
+                       void* stream);
+
+/* GriffinLim(power=1, n_iter, momentum, length=None) on 3-column magnitudes.
+ *   mag [dev][B][3][K]; init_angles [dev][B][3][K] complex or NULL; when NULL the initial phases are drawn
+ *   on the device (real, imag ~ U[0,1) independently, as the reference's torch.rand(complex64)) from a
+ *   counter-based generator keyed by (seed, stream_id0 + b, element), so results do not depend on how
+ *   streams are sharded.  scale [dev][B] or NULL multiplies the output (the `* peak` of app3.py:217).
+ *   wave [dev][B][n_fft]. */
+int dn_griffinlim(const dn_dsp* d, const float* mag, const float* init_angles, uint64_t seed,
+                  uint64_t stream_id0, const float* scale, float* wave, int32_t B, int32_t n_iter,
+                  float momentum, void* stream);
+
+/* torch.istft(center=True, length=None) of 3 columns: spec [dev][B][3][K] complex -> wave [dev][B][n_fft]. */
+int dn_istft(const dn_dsp* d, const float* spec, float* wave, int32_t B, void* stream);
+
+/* Scratch the fused entry points need, in bytes, for a batch of B streams. */
+size_t dn_workspace_bytes(const dn_dsp* d, int32_t B);
+
+/* The whole per-hop body for B streams (app3.py:178-217): frames [dev][B][n_fft] raw samples,
+ * hx [dev][B][17][C] in/out, out [dev][B][n_fft] = GriffinLim(...) * peak.
+ * mel_residual_out [dev][B][3][M] or NULL receives the model output (predicted_diff_mel).
+ * workspace [dev] of dn_workspace_bytes(d, B) bytes. */
+int dn_process_frame(const dn_model* m, const dn_dsp* d, const float* frames, float* hx, float* out,
+                     float* mel_residual_out, const float* init_angles, uint64_t seed, uint64_t stream_id0,
+                     int32_t n_iter, float momentum, void* workspace, int32_t B, void* stream);
+
+/* Streaming step (app3.py:178-226): ring [dev][B][n_fft] holds the last n_fft input samples per stream;
+ * hop_in [dev][B][hop] new samples are shifted in first.  ola [dev][B][n_fft] is the output
+ * overlap-add buffer; hop_out [dev][B][hop] receives ola[:hop] before the shift (app3.py:219-224). */
+int dn_stream_step(const dn_model* m, const dn_dsp* d, const float* hop_in, float* ring, float* ola, float* hx,
+                   float* hop_out, const float* init_angles, uint64_t seed, uint64_t stream_id0, int32_t n_iter,
+                   float momentum, void* workspace, int32_t B, void* stream);
+
+const char* dn_last_error(void);
+int dn_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DN_DENOISE_H */

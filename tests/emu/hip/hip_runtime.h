@@ -1,0 +1,118 @@
+// TEST INFRASTRUCTURE ONLY -- a functional stand-in for <hip/hip_runtime.h> that lets g++
+// compile the package's .hip kernel sources for the HOST so kernel *logic* (index maths, FFT
+// passes, LDS hand-offs) can be checked in the GPU-less build container:
+//   * one workgroup at a time; one std::thread per work-item
+//   * __syncthreads -> a workgroup barrier; wave-level primitives -> per-64-thread barriers
+//   * __shared__ -> static storage (valid because workgroups run one after another)
+//   * hipMalloc/hipMemcpy/... -> malloc/memcpy
+// Nothing in the product (audio-denoising_amd/) includes or links this; the shipped library is
+// built by hipcc from the same sources against the real HIP headers.  It proves nothing about
+// memory-model races or performance -- that is what the -m gpu tests are for.
+#pragma once
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <condition_variable>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <tuple>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __shared__ static
+#define __launch_bounds__(...)
+
+struct float2 { float x, y; };
+struct float4 { float x, y, z, w; };
+inline float2 make_float2(float x, float y) { return float2{x, y}; }
+inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+
+typedef int hipError_t;
+constexpr hipError_t hipSuccess = 0;
+typedef struct dn_emu_stream* hipStream_t;
+enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
+inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n); return *p ? 0 : 1; }
+inline hipError_t hipFree(void* p) { free(p); return 0; }
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return 0; }
+inline hipError_t hipGetLastError() { return 0; }
+inline const char* hipGetErrorString(hipError_t) { return "emulated"; }
+
+namespace dn_emu {
+
+class Barrier {
+    std::mutex m_;
+    std::condition_variable cv_;
+    int n_, count_ = 0, gen_ = 0;
+public:
+    explicit Barrier(int n) : n_(n) {}
+    void wait() {
+        std::unique_lock<std::mutex> lk(m_);
+        int g = gen_;
+        if (++count_ == n_) { count_ = 0; ++gen_; cv_.notify_all(); }
+        else cv_.wait(lk, [&] { return gen_ != g; });
+    }
+};
+
+struct Ctx {
+    Barrier* block;
+    Barrier* wave;
+    float* shfl;          // per-wave 64-slot scratch
+};
+inline thread_local Ctx ctx;
+inline thread_local dim3 tIdx, bIdx, bDim, gDim;
+
+template <typename K, typename... A>
+void launch(K kernel, dim3 grid, dim3 block, A... args) {
+    const int nt = (int)block.x, nw = (nt + 63) / 64;
+    for (unsigned bx = 0; bx < grid.x; ++bx) {
+        Barrier bb(nt);
+        std::vector<std::unique_ptr<Barrier>> wb;
+        std::vector<std::vector<float>> ws(nw, std::vector<float>(64));
+        for (int w = 0; w < nw; ++w) wb.emplace_back(new Barrier(std::min(64, nt - 64 * w)));
+        std::vector<std::thread> th;
+        for (int t = 0; t < nt; ++t)
+            th.emplace_back([&, t] {
+                ctx = Ctx{&bb, wb[t / 64].get(), ws[t / 64].data()};
+                tIdx = dim3(t); bIdx = dim3(bx); bDim = block; gDim = grid;
+                kernel(args...);
+            });
+        for (auto& x : th) x.join();
+    }
+}
+
+inline float shfl(float v, int src) {
+    ctx.shfl[tIdx.x & 63] = v;
+    ctx.wave->wait();
+    float r = ctx.shfl[src & 63];
+    ctx.wave->wait();
+    return r;
+}
+
+}  // namespace dn_emu
+
+#define threadIdx dn_emu::tIdx
+#define blockIdx dn_emu::bIdx
+#define blockDim dn_emu::bDim
+#define gridDim dn_emu::gDim
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) dn_emu::launch(kernel, grid, block, __VA_ARGS__)
+
+inline void __syncthreads() { dn_emu::ctx.block->wait(); }
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
+#define __builtin_amdgcn_wave_barrier() dn_emu::ctx.wave->wait()
+#define __builtin_amdgcn_readfirstlane(x) (x)
+inline float __shfl_xor(float v, int mask) { return dn_emu::shfl(v, (int)(dn_emu::tIdx.x & 63) ^ mask); }
+inline float __shfl(float v, int src) { return dn_emu::shfl(v, src); }
+using std::max;
+using std::min;
