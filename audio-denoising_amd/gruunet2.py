@@ -1,0 +1,161 @@
+"""Drop-in ``GRUUNet2`` for the reference's ``gruunet2.GRUUNet2`` (gruunet2.py:246-306).
+
+Same constructor, same ``forward(input, hx=None) -> (out, hx)``, same ``state_dict`` keys (so the
+reference checkpoints load with ``load_state_dict``), same ``hparams`` / ``get_config()`` /
+``latent_size`` / ``num_compressed_bins`` attributes the callers use (app3.py:112-116,200-201;
+app.py:86,97,99; server.py:151,212).  The forward itself is one fused HIP kernel per call
+(``dn_cell_forward``); tensors must live on the GPU.  There is NO CPU / eager-PyTorch fallback:
+a CPU tensor or a missing extension raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import weakref
+
+import torch
+from torch import nn
+
+from . import _lib
+
+_H = 17  # hidden channels the kernels are built for
+
+
+class _Holder(nn.Module):
+    """Parameter container; never called."""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("parameter holder; the forward pass runs in the HIP extension")
+
+
+class _ConvBlock(_Holder):
+    def __init__(self, conv: nn.Module):
+        super().__init__()
+        self.conv = conv
+
+
+class _Smear(_Holder):
+    def __init__(self, num_gaussians: int):
+        super().__init__()
+        self.register_buffer("offset", torch.linspace(0.0, 1.0, num_gaussians))   # gruunet2.py:62-64
+
+
+class _Blocks(_Holder):
+    def __init__(self, key: str, convs, num_gaussians: int):
+        super().__init__()
+        setattr(self, key, nn.ModuleList([_ConvBlock(c) for c in convs]))
+        self.gs = _Smear(num_gaussians)
+
+
+class _Cell(_Holder):
+    """Parameter layout of GRUUNetCell (gruunet2.py:202-227)."""
+
+    def __init__(self, in_size, hidden_sizes, kernel_sizes, strides, paddings, num_gaussians):
+        super().__init__()
+        g = num_gaussians
+        hs = list(hidden_sizes)
+        enc_out = hs[:-1] + [3 * hs[-1]]
+        enc_in = [in_size] + hs[:-1]
+        self.input_gate = _Blocks("downs", [
+            nn.Conv1d(ci + g, co, kernel_size=k, stride=s, padding=p)
+            for ci, co, k, s, p in zip(enc_in, enc_out, kernel_sizes, strides, paddings)], g)
+        self.reset_gate = _Blocks("downs", [nn.Conv1d(hs[-1] + g, 3 * hs[-1], kernel_size=3, stride=1, padding=1)], g)
+        sizes = [1] + hs                      # UpBlocks(in_size, hidden_sizes, output_size=1, ...)
+        rs, rk, rst, rp = sizes[::-1], list(kernel_sizes)[::-1], list(strides)[::-1], list(paddings)[::-1]
+        self.output_gate = _Blocks("ups", [
+            nn.ConvTranspose1d((rs[i] if i == 0 else 2 * rs[i]) + g, rs[i + 1], kernel_size=rk[i], stride=rst[i], padding=rp[i])
+            for i in range(len(hs))], g)
+
+
+class GRUUNet2(nn.Module):
+    def __init__(self, num_compressed_bins, in_size, hidden_sizes, kernel_sizes, strides, paddings, num_gaussians=6):
+        super().__init__()
+        assert in_size == 1                                       # gruunet2.py:257
+        # what the reference's auto_save_hyperparams decorator records (gruunet2.py:29-51)
+        self.hparams = dict(num_compressed_bins=num_compressed_bins, in_size=in_size, hidden_sizes=hidden_sizes,
+                            kernel_sizes=kernel_sizes, strides=strides, paddings=paddings, num_gaussians=num_gaussians)
+        self.latent_size = hidden_sizes[-1]
+        self.num_compressed_bins = num_compressed_bins
+        self.cell = _Cell(in_size, hidden_sizes, kernel_sizes, strides, paddings, num_gaussians)
+        self._supported = (len(hidden_sizes) == 4 and all(h == _H for h in hidden_sizes) and
+                           all(k == 3 for k in kernel_sizes) and all(s == 2 for s in strides) and
+                           all(p == 1 for p in paddings) and num_gaussians == 6)
+
+    def get_config(self):
+        return self.hparams
+
+    # ------------------------------------------------------------------ native handle
+    def _flat_weights(self) -> torch.Tensor:
+        """state_dict flattened in key order: the blob layout dn_model_create expects."""
+        return torch.cat([v.detach().reshape(-1).to(device="cpu", dtype=torch.float32) for v in self.state_dict().values()])
+
+    def _native(self, device: torch.device):
+        tensors = list(self.state_dict(keep_vars=True).values())
+        key = tuple((t.data_ptr(), t._version) for t in tensors)
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        per_model = _NATIVE.setdefault(self, {})
+        hit = per_model.get(idx)
+        if hit is not None and hit.key == key:
+            return hit.handle
+        if not self._supported:
+            raise NotImplementedError(
+                "the HIP kernels are built for the architecture of the reference's GRUUNet2 checkpoints "
+                "(4 levels, hidden 17, kernel 3, stride 2, padding 1, 6 gaussians); got " + repr(self.hparams))
+        lib = _lib.get_lib()
+        blob = self._flat_weights().contiguous()
+        cfg = _lib.ModelCfg(int(self.num_compressed_bins), 1, 4, _H, 3, 2, 1, 6)
+        handle = C.c_void_p()
+        with torch.cuda.device(idx):
+            lib.check(lib.dn_model_create(C.c_void_p(blob.data_ptr()), blob.numel(), C.byref(cfg), C.byref(handle)))
+        per_model[idx] = _NativeModel(lib, key, handle)     # a replaced entry is destroyed by its finalizer
+        return handle
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, input, hx=None):
+        """input (B,T,F) or (T,F); hx (B,H,C) or None -> (out like input, hx (B,H,C)).  gruunet2.py:290-306."""
+        two_dimmed = input.dim() == 2
+        if two_dimmed:
+            input = input.unsqueeze(0)
+        if input.dim() != 3:
+            raise RuntimeError(f"expected a (B,T,F) or (T,F) input, got {tuple(input.shape)}")
+        if not input.is_cuda:
+            raise RuntimeError("GRUUNet2 (MI355X build) runs on the GPU only: move the model and its input to a "
+                               "'cuda' device; there is no CPU path in this package")
+        if input.dtype != torch.float32:
+            raise TypeError(f"the HIP kernels compute in float32; got {input.dtype}")
+        B, T, F = input.shape
+        if hx is None:
+            hx = torch.zeros(B, self.latent_size, self.num_compressed_bins, dtype=input.dtype, device=input.device)
+        if hx.dim() != 3 or hx.shape[0] != B or hx.shape[1] != self.latent_size:
+            raise RuntimeError(f"hx must be ({B}, {self.latent_size}, C); got {tuple(hx.shape)}")
+        if hx.device != input.device or hx.dtype != input.dtype:
+            raise RuntimeError("hx must have the dtype and device of the input")
+        Cb = hx.shape[2]
+        if F != 16 * Cb:
+            # the reference fails at `i_i + h_i` with a broadcast error (gruunet2.py:236)
+            raise RuntimeError(f"The size of tensor a ({F // 16}) must match the size of tensor b ({Cb}) at non-singleton "
+                               f"dimension 2 (input of {F} bins compresses to {F // 16}, hx has {Cb})")
+        lib = _lib.get_lib()
+        handle = self._native(input.device)
+        x = input.detach().contiguous()
+        h0 = hx.detach().contiguous()
+        out = torch.empty_like(x)
+        h1 = torch.empty_like(h0)
+        with torch.cuda.device(input.device):
+            stream = torch.cuda.current_stream().cuda_stream
+            lib.check(lib.dn_cell_forward(handle, x.data_ptr(), h0.data_ptr(), out.data_ptr(), h1.data_ptr(),
+                                          B, T, F, Cb, C.c_void_p(stream)))
+        if two_dimmed:
+            out = out.squeeze(0)
+        return out, h1
+
+
+class _NativeModel:
+    """Owns one dn_model*; destroyed exactly once when dropped."""
+
+    def __init__(self, lib, key, handle):
+        self.key, self.handle = key, handle
+        self._fin = weakref.finalize(self, lib.dn_model_destroy, handle)
+
+
+# model -> {device index: _NativeModel}; kept outside the module so copy/deepcopy never duplicates a handle
+_NATIVE: "weakref.WeakKeyDictionary[GRUUNet2, dict]" = weakref.WeakKeyDictionary()

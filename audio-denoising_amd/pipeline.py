@@ -1,0 +1,154 @@
+"""The per-hop pipeline of the reference's ``DenoisingAudioProcessor.recv`` loop body
+(app3.py:178-226 == app2.py:185-233), batched over B independent streams and fused behind
+``dn_process_frame`` / ``dn_stream_step``.
+
+``Denoiser.process_frame`` is the new name for that loop body:
+peak-normalise, Hann, 3-column STFT, mel, log1p, GRUUNet2 (3 steps), residual, expm1, inverse mel,
+32-iteration Griffin-Lim, ``* peak`` -- P1..P12 of SURVEY.md section 8(a).  ``DenoiserStream`` adds the
+per-stream state the reference keeps in ``input_buffer`` / ``output_ola_buffer`` / ``hx``
+(app3.py:130-133), resident on the GPU.  No CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .gruunet2 import GRUUNet2
+from .transforms import DspPlan, melscale_fbanks
+
+
+class Denoiser:
+    """Batched, fused hop pipeline bound to one model and one DSP plan on one GPU."""
+
+    def __init__(self, model: GRUUNet2, sample_rate: int, n_fft: int = 1024, hop_length: int = 512, n_mels: int = 80,
+                 n_iter: int = 32, momentum: float = 0.99, device=None):
+        self.device = torch.device(device if device is not None else next(model.parameters()).device)
+        if self.device.type != "cuda":
+            raise RuntimeError("Denoiser needs a 'cuda' device; there is no CPU path in this package")
+        if n_mels % 16 != 0:
+            raise ValueError("n_mels must be a multiple of 16 (four stride-2 encoder levels)")
+        self.lib = _lib.get_lib()
+        self.model = model
+        self.sample_rate, self.n_fft, self.hop, self.n_mels = sample_rate, n_fft, hop_length, n_mels
+        self.n_stft = n_fft // 2 + 1
+        self.n_iter, self.momentum = int(n_iter), float(momentum)
+        self.num_compressed_bins = n_mels // 16
+        # the same construction-time tensors the reference's transforms build (app3.py:135-155)
+        fb = melscale_fbanks(self.n_stft, 0.0, float(sample_rate // 2), n_mels, sample_rate)
+        self.plan = DspPlan(self.device, sample_rate, n_fft, hop_length, n_mels, fb=fb, window=torch.hann_window(n_fft))
+        self._ws = None
+        self._calls = 0
+
+    # -- helpers
+    def _workspace(self, batch: int) -> torch.Tensor:
+        need = self.plan.workspace_bytes(batch)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def init_hx(self, batch: int) -> torch.Tensor:
+        """zeros(B, 17, C): app3.py:158-165."""
+        return torch.zeros(batch, self.model.latent_size, self.num_compressed_bins, dtype=torch.float32, device=self.device)
+
+    def _check(self, t, shape, name, dtype=torch.float32):
+        if not t.is_cuda or t.device != self.device:
+            raise RuntimeError(f"{name} must live on {self.device} (no CPU path)")
+        if t.dtype != dtype or tuple(t.shape) != shape or not t.is_contiguous():
+            raise ValueError(f"{name} must be contiguous {dtype} of shape {shape}; got {t.dtype} {tuple(t.shape)}")
+
+    def _angles_ptr(self, init_angles, batch):
+        """(B, K, 3) complex64 as the reference draws it -> [B][3][K] interleaved storage."""
+        if init_angles is None:
+            return None, None
+        if tuple(init_angles.shape) != (batch, self.n_stft, 3) or init_angles.dtype != torch.complex64:
+            raise ValueError(f"init_angles must be complex64 of shape {(batch, self.n_stft, 3)}")
+        ia = torch.view_as_real(init_angles.to(self.device).transpose(-1, -2).contiguous())
+        return ia, ia.data_ptr()
+
+    # -- the hop body
+    def process_frame(self, frames: torch.Tensor, hx: torch.Tensor | None = None, init_angles: torch.Tensor | None = None,
+                      seed: int | None = None, stream_id0: int = 0, return_residual: bool = False):
+        """frames (B, n_fft) raw samples, hx (B,17,C) or None -> (out (B, n_fft), hx_new[, predicted_diff_mel (B,3,M)]).
+
+        ``hx`` is not modified (the reference rebinds ``self.hx`` to the returned tensor, app3.py:201)."""
+        B = frames.shape[0]
+        self._check(frames, (B, self.n_fft), "frames")
+        hx_new = self.init_hx(B) if hx is None else hx.clone()
+        self._check(hx_new, (B, self.model.latent_size, self.num_compressed_bins), "hx")
+        out = torch.empty_like(frames)
+        resid = torch.empty(B, 3, self.n_mels, dtype=torch.float32, device=self.device) if return_residual else None
+        keep, ia_ptr = self._angles_ptr(init_angles, B)
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if init_angles is None else 0
+        ws = self._workspace(B)
+        model_h = self.model._native(self.device)
+        with torch.cuda.device(self.device):
+            st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            self.lib.check(self.lib.dn_process_frame(model_h, self.plan.handle, frames.data_ptr(), hx_new.data_ptr(), out.data_ptr(),
+                                                     None if resid is None else resid.data_ptr(), ia_ptr, seed, stream_id0,
+                                                     self.n_iter, self.momentum, ws.data_ptr(), B, st))
+        return (out, hx_new, resid) if return_residual else (out, hx_new)
+
+    def process_frame_(self, frames: torch.Tensor, hx: torch.Tensor, out: torch.Tensor, seed: int = 0, stream_id0: int = 0) -> None:
+        """Allocation-free variant for steady-state loops and hipGraph capture: ``hx`` is advanced in place and
+        the denoised frames are written to ``out``; initial phases come from the device generator."""
+        B = frames.shape[0]
+        ws = self._workspace(B)
+        model_h = self.model._native(self.device)
+        st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        self.lib.check(self.lib.dn_process_frame(model_h, self.plan.handle, frames.data_ptr(), hx.data_ptr(), out.data_ptr(), None, None,
+                                                 seed, stream_id0, self.n_iter, self.momentum, ws.data_ptr(), B, st))
+
+
+class DenoiserStream:
+    """B concurrent streams with persistent device state: input ring, output overlap-add buffer, hx.
+
+    ``push(chunk)`` mirrors one ``recv`` call of the reference for every stream at once
+    (app3.py:174-226): append samples, run one hop per ``hop_length`` new samples once ``n_fft``
+    samples are buffered, return the emitted output samples."""
+
+    def __init__(self, denoiser: Denoiser, batch: int, stream_id0: int = 0, seed: int = 0):
+        self.dn, self.batch, self.stream_id0, self.seed = denoiser, batch, stream_id0, seed
+        d = denoiser
+        dev = d.device
+        self.ring = torch.zeros(batch, d.n_fft, dtype=torch.float32, device=dev)
+        self.ola = torch.zeros(batch, d.n_fft, dtype=torch.float32, device=dev)     # app3.py:133
+        self.hx = d.init_hx(batch)
+        self.pending = torch.zeros(batch, 0, dtype=torch.float32, device=dev)      # samples not yet shifted in
+        self.filled = 0          # samples accepted so far, saturating at n_fft - hop (priming)
+        self.hops = 0
+
+    def push(self, chunk: torch.Tensor, init_angles_per_hop=None) -> torch.Tensor:
+        d = self.dn
+        if chunk.device != d.device or chunk.dtype != torch.float32 or chunk.shape[0] != self.batch:
+            raise ValueError("chunk must be float32 (B, n) on the denoiser's device")
+        self.pending = torch.cat([self.pending, chunk], dim=1)
+        prime = d.n_fft - d.hop
+        if self.filled < prime:                  # the first frame needs n_fft samples: fill ring[hop:] first
+            take = min(prime - self.filled, self.pending.shape[1])
+            self.ring[:, d.hop + self.filled: d.hop + self.filled + take] = self.pending[:, :take]
+            self.pending = self.pending[:, take:]
+            self.filled += take
+        outs = []
+        ws = d._workspace(self.batch)
+        model_h = d.model._native(d.device)
+        i = 0
+        while self.filled == prime and self.pending.shape[1] >= d.hop:
+            hop_in = self.pending[:, :d.hop].contiguous()
+            self.pending = self.pending[:, d.hop:]
+            hop_out = torch.empty(self.batch, d.hop, dtype=torch.float32, device=d.device)
+            ia = None if init_angles_per_hop is None else init_angles_per_hop[i]
+            keep, ia_ptr = d._angles_ptr(ia, self.batch)
+            with torch.cuda.device(d.device):
+                st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+                d.lib.check(d.lib.dn_stream_step(model_h, d.plan.handle, hop_in.data_ptr(), self.ring.data_ptr(), self.ola.data_ptr(),
+                                                 self.hx.data_ptr(), hop_out.data_ptr(), ia_ptr, self.seed + self.hops, self.stream_id0,
+                                                 d.n_iter, d.momentum, ws.data_ptr(), self.batch, st))
+            outs.append(hop_out)
+            self.hops += 1
+            i += 1
+        if not outs:
+            return torch.zeros(self.batch, 0, dtype=torch.float32, device=d.device)
+        return torch.cat(outs, dim=1)

@@ -1,0 +1,123 @@
+"""CPU tier: host logic of the drop-in boundary, and that the HIP shared library loads and exports
+every symbol include/dn_denoise.h declares (no compute calls without a GPU)."""
+import ctypes
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, REPO
+
+CFG = dict(in_size=1, hidden_sizes=(17, 17, 17, 17), kernel_sizes=(3, 3, 3, 3), strides=(2, 2, 2, 2), paddings=(1, 1, 1, 1))
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    import __graft_entry__ as ge
+    ge.build()                       # hipcc cross-compiles gfx950 without a GPU
+    from audio_denoising_amd import _lib
+    return _lib.get_lib()
+
+
+def test_header_symbols_are_all_exported(built_lib):
+    from audio_denoising_amd import _lib
+    hdr = open(os.path.join(REPO, "include", "dn_denoise.h")).read()
+    declared = set(re.findall(r"\b(dn_[a-z0-9_]+)\s*\(", hdr)) - {"dn_workspace_bytes(d"}
+    declared = {d for d in declared if not d.endswith("_t")}
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    raw = ctypes.CDLL(built_lib.path)
+    for sym in declared:
+        assert hasattr(raw, sym), sym
+    assert built_lib.dn_abi_version() == _lib.ABI_VERSION
+
+
+def test_library_is_a_gfx950_code_object(built_lib):
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/clang-offload-bundler", "--list", "--type=o", f"--input={built_lib.path}"],
+                         capture_output=True, text=True)
+    listing = out.stdout + out.stderr
+    if out.returncode != 0 or "gfx" not in listing:     # fall back to scanning the fat binary's target string
+        listing = subprocess.run(["strings", built_lib.path], capture_output=True, text=True).stdout
+    assert "gfx950" in listing
+
+
+def test_bad_arguments_fail_with_messages_not_crashes(built_lib):
+    from audio_denoising_amd._lib import DnError, DspCfg
+    h = ctypes.c_void_p()
+    rc = built_lib.dn_dsp_create(ctypes.byref(DspCfg(48000, 1536, 768, 64)), None, None, None, ctypes.byref(h))
+    assert rc == -2 and b"1024" in built_lib.dn_last_error()      # mixed-radix n_fft=1536 not built yet: loud, not silent
+    with pytest.raises(DnError):
+        built_lib.check(built_lib.dn_cell_forward(None, None, None, None, None, 1, 1, 64, 4, None))
+    assert built_lib.dn_workspace_bytes(None, 4) == 0
+
+
+def test_module_mirrors_reference_interface():
+    from gruunet2 import GRUUNet2                      # app3.py:38
+    manifest = json.load(open(os.path.join(GOLDEN, "weights_manifest.json")))["dari_tult"]
+    m = GRUUNet2(num_compressed_bins=4, **CFG)
+    assert isinstance(m, torch.nn.Module)
+    assert [[k, list(v.shape)] for k, v in m.state_dict().items()] == manifest["keys"]
+    assert m.latent_size == 17 and m.num_compressed_bins == 4
+    assert m.get_config() is m.hparams and list(m.hparams) == ["num_compressed_bins", "in_size", "hidden_sizes", "kernel_sizes",
+                                                                "strides", "paddings", "num_gaussians"]
+    assert m.hparams["num_gaussians"] == 6
+    assert sum(p.numel() for p in m.parameters()) == 15319       # learnable parameters
+    m.eval()
+    with pytest.raises(AssertionError):
+        GRUUNet2(num_compressed_bins=4, **{**CFG, "in_size": 2})  # gruunet2.py:257
+
+
+def test_checkpoint_blob_round_trips_through_load_state_dict():
+    from gruunet2 import GRUUNet2
+    from oracle import model_ref
+    blob = np.fromfile(os.path.join(GOLDEN, "weights_dari_tult.bin"), dtype=np.float32)
+    m = GRUUNet2(num_compressed_bins=5, **CFG)
+    m.load_state_dict(model_ref.unflatten_weights(blob))
+    assert np.array_equal(m._flat_weights().numpy(), blob)
+
+
+def test_cpu_tensors_and_unsupported_configs_fail_loudly():
+    from gruunet2 import GRUUNet2
+    m = GRUUNet2(num_compressed_bins=4, **CFG)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        m(torch.zeros(1, 3, 64))
+    with pytest.raises(RuntimeError, match="GPU only"):
+        m(torch.zeros(3, 64))
+    from audio_denoising_amd import transforms as T
+    with pytest.raises(RuntimeError, match="CUDA"):
+        T.Spectrogram(power=None, n_fft=1024, win_length=1024, hop_length=512)(torch.zeros(1, 1024))
+    with pytest.raises(NotImplementedError):
+        T.Spectrogram(power=None, n_fft=1536, win_length=1536, hop_length=768)
+    with pytest.raises(ValueError):
+        T.GriffinLim(n_fft=1024, momentum=1.5)
+
+
+def test_transform_constructors_build_the_reference_filterbank():
+    from audio_denoising_amd import transforms as T
+    from oracle import dsp_ref
+    for sr, n_mels in ((16000, 80), (48000, 64)):
+        m = T.MelScale(n_mels=n_mels, n_stft=513, sample_rate=sr)
+        assert torch.equal(m.fb, dsp_ref.melscale_fbanks(513, n_mels, sr))
+        inv = T.InverseMelScale(n_mels=n_mels, n_stft=513, sample_rate=sr)
+        assert torch.equal(inv.fb, m.fb)
+    assert torch.equal(T.GriffinLim(n_fft=1024, win_length=1024, hop_length=512, power=1.0).window, torch.hann_window(1024))
+
+
+def test_missing_extension_is_an_import_error(tmp_path):
+    from audio_denoising_amd._lib import DnLib
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        DnLib(str(tmp_path / "libdn_denoise.so"))
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(REPO, "audio-denoising_amd")
+    for root, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(root, fn)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), fn
+                assert "tests/emu" not in src and "dn_emu" not in src, fn
