@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""Headline benchmark: denoised 32 ms frames/s (16 kHz, n_fft 1024, hop 512, 80 mels) at batch 256 per GPU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the whole per-hop path (P1..P12 of SURVEY.md section 8a: peak-normalise, Hann,
+3-column STFT, mel, log1p, GRUUNet2 x3 steps, residual, expm1, inverse mel, 32-iteration Griffin-Lim,
+`* peak`) over one batch of 256 synthetic frames per GPU, inputs resident in HBM, hidden state carried
+from step to step.  Streams are independent, so N GPUs run N x 256 streams with no data-path collective
+(weak scaling); the only collectives are the barriers and the MAX of the elapsed time.
+
+Besides the contract fields the JSON line carries
+  roofline     -- the dominant kernel (griffinlim_kernel): algorithmic FLOPs per launch / its average launch
+                  duration measured with HIP events in this process, against the fp32 compute peak;
+  cpu_baseline -- the CPU oracle (the reference's op sequence restated on torch-CPU, oracle/pipeline_ref.py)
+                  timed on this host's cores on a bounded sample of the same workload (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+BATCH = 256
+SR, N_FFT, HOP, N_MELS = 16000, 1024, 512, 80
+N_STFT = N_FFT // 2 + 1
+GL_ITERS = 32
+# algorithmic work per frame (real FFT of length N counted as 2.5 N log2 N = 25,600 flop)
+FLOP_PER_RFFT = 2.5 * N_FFT * 10
+GL_FFTS = GL_ITERS * 6 + 3
+GL_FLOP_PER_FRAME = GL_FFTS * FLOP_PER_RFFT                       # 4.992 MFLOP
+TOTAL_FLOP_PER_FRAME = 198 * FLOP_PER_RFFT + 2 * 246240 + 939150  # 6.50 MFLOP
+HBM_BYTES_PER_FRAME = 4 * N_FFT + 4 * N_FFT + 2 * 4 * 17 * 5       # 8,872 B compulsory
+GL_HBM_BYTES_PER_FRAME = 4 * 3 * N_STFT + 4 * N_FFT + 4            # kernel-level: magnitudes in, waveform out, peak
+PEAK_FP32_TFLOPS = 157.3                                          # MI355X_MICROARCH.md: vector == matrix fp32 peak
+PEAK_HBM_GBS = 8000.0
+
+
+def build_denoiser(dev):
+    from audio_denoising_amd.gruunet2 import GRUUNet2
+    from audio_denoising_amd.pipeline import Denoiser
+    blob = np.fromfile(os.path.join(REPO, "tests", "golden", "weights_dari_tult.bin"), dtype=np.float32)
+    model = GRUUNet2(5, 1, (17, 17, 17, 17), (3, 3, 3, 3), (2, 2, 2, 2), (1, 1, 1, 1))
+    keys = list(model.state_dict().keys())
+    sd, off = {}, 0
+    for k in keys:
+        n = model.state_dict()[k].numel()
+        sd[k] = torch.from_numpy(blob[off:off + n].copy()).reshape(model.state_dict()[k].shape)
+        off += n
+    model.load_state_dict(sd)
+    model.eval().to(dev)
+    return Denoiser(model, SR, N_FFT, HOP, N_MELS, n_iter=GL_ITERS)
+
+
+def staged_kernel_times(dn, frames, hx, steps):
+    """The same four launches dn_process_frame makes, issued one ABI call each with HIP events in between
+    (torch.cuda.Event on the stream the kernels are launched on).  Returns mean ms per kernel."""
+    import ctypes as C
+    from audio_denoising_amd import _lib
+    lib, plan, dev = dn.lib, dn.plan, dn.device
+    B = frames.shape[0]
+    mel = torch.empty(B, 3, N_MELS, device=dev)
+    diff = torch.empty_like(mel)
+    lin = torch.empty(B, 3, N_STFT, device=dev)
+    peak = torch.empty(B, device=dev)
+    out = torch.empty_like(frames)
+    model_h = dn.model._native(dev)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    names = ["stft_mel_log1p", "cell", "residual_invmel", "griffinlim"]
+    acc = dict.fromkeys(names, 0.0)
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(steps)]
+    for s in range(steps):
+        e = ev[s]
+        e[0].record()
+        lib.check(lib.dn_stft_mel_log1p(plan.handle, frames.data_ptr(), mel.data_ptr(), peak.data_ptr(), B,
+                                        _lib.DN_PEAK_NORMALIZE | _lib.DN_PRE_WINDOW, st))
+        e[1].record()
+        lib.check(lib.dn_cell_forward(model_h, mel.data_ptr(), hx.data_ptr(), diff.data_ptr(), hx.data_ptr(), B, 3, N_MELS, N_MELS // 16, st))
+        e[2].record()
+        lib.check(lib.dn_residual_invmel(plan.handle, mel.data_ptr(), diff.data_ptr(), lin.data_ptr(), B, 3, st))
+        e[3].record()
+        lib.check(lib.dn_griffinlim(plan.handle, lin.data_ptr(), None, 7 + s, 0, peak.data_ptr(), out.data_ptr(), B, GL_ITERS, 0.99, st))
+        e[4].record()
+    torch.cuda.synchronize()
+    for s in range(steps):
+        for i, n in enumerate(names):
+            acc[n] += ev[s][i].elapsed_time(ev[s][i + 1])
+    return {n: acc[n] / steps for n in names}
+
+
+def cpu_baseline(budget_s=20.0):
+    """The reference's op sequence on the host CPU (oracle, kind 'port'), batch 256 and batch 1."""
+    from oracle import dsp_ref, model_ref, pipeline_ref
+    p = pipeline_ref.PARAMS_S
+    sd = model_ref.unflatten_weights(np.fromfile(os.path.join(REPO, "tests", "golden", "weights_dari_tult.bin"), dtype=np.float32))
+    fb = dsp_ref.melscale_fbanks(p.n_stft, p.n_mels, p.sample_rate)
+    # the GPU box gives one-GPU jobs a 16-core share of a much larger host: size the thread pool to the share
+    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("DN_CPU_THREADS", "16")))
+    torch.set_num_threads(cores)
+    res = {}
+    for B, share in ((BATCH, 0.75), (1, 0.25)):
+        g = torch.Generator().manual_seed(1234)
+        frames = 0.1 * torch.randn(B, p.n_fft, generator=g)
+        hx = torch.zeros(B, 17, 5)
+        gen = torch.Generator().manual_seed(4321)
+        with torch.no_grad():
+            tw = time.perf_counter()
+            r = pipeline_ref.process_frame(sd, frames, hx, p, fb, generator=gen)     # warm-up
+            hx = r["hx"]
+            print(f"[bench] cpu baseline B={B}: warm-up step {time.perf_counter() - tw:.2f} s on {cores} threads", file=sys.stderr, flush=True)
+            n, t0 = 0, time.perf_counter()
+            while True:
+                r = pipeline_ref.process_frame(sd, frames, hx, p, fb, generator=gen)
+                hx = r["hx"]
+                n += 1
+                el = time.perf_counter() - t0
+                if el >= budget_s * share or n >= 200:
+                    break
+        res[B] = (B * n / el, n, el)
+    v, n, el = res[BATCH]
+    return {"value": round(v, 1), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{n} steps of batch {BATCH} ({el:.1f} s) of the same synthetic workload through oracle/pipeline_ref.process_frame "
+                      f"(torch-CPU stft/matmul/conv1d/lstsq(gels)/32-iter Griffin-Lim, {cores} threads)",
+            "batch1_value": round(res[1][0], 1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=BATCH, help="streams per GPU (the metric is quoted at 256)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hop path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from audio_denoising_amd.shard import shard_range
+    dn = build_denoiser(dev)
+    B = args.batch
+    lo, hi = shard_range(B * world, world, rank)          # this rank's global stream ids
+    g = torch.Generator().manual_seed(1234 + rank)
+    frames = (0.1 * torch.randn(B, N_FFT, generator=g)).to(dev)
+    hx = dn.init_hx(B)
+    out = torch.empty_like(frames)
+
+    def step(i):
+        dn.process_frame_(frames, hx, out, seed=1000 + i, stream_id0=lo)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(out).all()
+    if rank == 0:
+        print(f"[bench] {args.steps} steps x {B * world} frames in {elapsed:.4f} s", file=sys.stderr, flush=True)
+
+    line = None
+    if rank == 0:
+        ms = 1e3 * elapsed / args.steps
+        value = B * world * args.steps / elapsed
+        kt = staged_kernel_times(dn, frames, hx, min(args.steps, 100))
+        gl_s = kt["griffinlim"] * 1e-3
+        ach = GL_FLOP_PER_FRAME * B / gl_s / 1e12
+        traffic = None
+        pmc = os.path.join(REPO, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            traffic = json.load(open(pmc)).get("griffinlim_kernel_hbm_bytes_per_launch")
+        line = {
+            "metric": "denoised audio frames/sec (32 ms, 16 kHz, hop 512) at batch 256; 1/2/4/8 GPU",
+            "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: batch 256 synthetic 32 ms frames per GPU, n_fft=1024 hop=512 n_mels=80, GRUUNet2 fp32 "
+                                   "(dari_tult weights, num_compressed_bins=5), 32-iter Griffin-Lim, device-RNG initial phases, hx carried",
+                       "streams_per_gpu": B, "frames_per_step": B * world, "sample_rate": SR, "n_fft": N_FFT, "hop": HOP,
+                       "n_mels": N_MELS, "griffinlim_iters": GL_ITERS, "parallelism": f"stream-sharded x{world} (no data-path collective)"},
+            "roofline": {"bound": "mfma", "kernel": "griffinlim_kernel", "achieved": round(ach, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(ach / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
+                         "note": "fp32 compute roof (FFT butterflies on the fp32 VALU; vector and matrix fp32 peaks are both 157.3 TF); "
+                                 "algorithmic = 195 rFFT-1024 x 25,600 flop per frame x 256 frames per launch",
+                         "launch_ms": round(kt["griffinlim"], 4),
+                         "hbm_frac": round(GL_HBM_BYTES_PER_FRAME * B / gl_s / 1e9 / PEAK_HBM_GBS, 6)},
+            "kernel_ms": {k: round(v, 4) for k, v in kt.items()},
+            "whole_path": {"tflops": round(TOTAL_FLOP_PER_FRAME * value / 1e12, 3),
+                           "fp32_frac": round(TOTAL_FLOP_PER_FRAME * value / 1e12 / (PEAK_FP32_TFLOPS * world), 4),
+                           "hbm_frac": round(HBM_BYTES_PER_FRAME * value / 1e9 / (PEAK_HBM_GBS * world), 6)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if line is not None:
+        print(json.dumps(line), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -194,7 +194,9 @@ def test_process_frame_matches_oracle_golden(dev, tag):
     assert np.abs(resid.cpu().numpy() - g["predicted_diff"]).max() <= TOL_RESIDUAL
     assert np.abs(hx.cpu().numpy() - g["hx"]).max() <= TOL_RESIDUAL
     assert np.sqrt(np.mean((out.cpu().numpy() - g["out"]) ** 2)) <= TOL_WAVE_RMS
-    assert torch.isfinite(out).all() and out[4].abs().max().item() == 0.0      # silent stream stays silent (app3.py:182-186)
+    # silent / sub-threshold streams (peak <= 1e-6 -> no normalisation, app3.py:182-186) stay finite and match the oracle
+    assert torch.isfinite(out).all()
+    assert np.abs(out.cpu().numpy()[4:6] - g["out"][4:6]).max() <= 1e-3
 
 
 def test_process_frame_full_batch_vs_oracle_sample_and_shard_invariance(dev):
