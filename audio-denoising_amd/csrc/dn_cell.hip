@@ -20,12 +20,11 @@
 namespace dn {
 
 constexpr int kCellThreads = 256;
-constexpr int kCellWaves = kCellThreads / 64;
 
 // ---- Conv1d k3 s2 p1 + folded position bias + relu.  in [TT][CIN][2*LOUT] -> out [TT][COUT][LOUT]
 // OG = output channels per wavefront.
 template <int CIN, int COUT, int OG>
-__device__ __forceinline__ void conv_down(const float* __restrict__ wgt, const float* __restrict__ bt,
+__device__ __forceinline__ void conv_down(cfloat_ptr wgt, const float* __restrict__ bt,
                                           const float* in, float* out, int lout, int tt, int wv, int lane) {
     const int lin = 2 * lout;
     const int o0 = wv * OG;
@@ -41,7 +40,7 @@ __device__ __forceinline__ void conv_down(const float* __restrict__ wgt, const f
             const float x0 = j > 0 ? xin[c * lin - 1] : 0.0f;
             const float x1 = xin[c * lin];
             const float x2 = xin[c * lin + 1];
-            const float* wc = wgt + c * 3 * COUT + o0;
+            cfloat_ptr wc = wgt + c * 3 * COUT + o0;
 #pragma unroll
             for (int oo = 0; oo < OG; ++oo) {
                 if (o0 + oo < COUT) {
@@ -61,7 +60,7 @@ __device__ __forceinline__ void conv_down(const float* __restrict__ wgt, const f
 // position bias.  a [TT][CA][L], skip [TT][CS][L] (CS may be 0) -> out [TT][COUT][2L], relu unless LAST.
 // Lane = (t, input position i) produces outputs 2i (tap k=1 of x[i]) and 2i+1 (k=2 of x[i], k=0 of x[i+1]).
 template <int CA, int CS, int COUT, int OG, bool LAST>
-__device__ __forceinline__ void conv_up(const float* __restrict__ wgt, const float* __restrict__ bt, const float* a,
+__device__ __forceinline__ void conv_up(cfloat_ptr wgt, const float* __restrict__ bt, const float* a,
                                         const float* skip, float* out, int l, int tt, int wv, int lane,
                                         size_t out_t_stride) {
     const int o0 = wv * OG;
@@ -82,7 +81,7 @@ __device__ __forceinline__ void conv_up(const float* __restrict__ wgt, const flo
             const float* src = c < CA ? a + ((size_t)t * CA + c) * l : skip + ((size_t)t * CS + (c - CA)) * l;
             const float x0 = src[i];
             const float x1 = has_next ? src[i + 1] : 0.0f;
-            const float* wc = wgt + c * 3 * COUT + o0;
+            cfloat_ptr wc = wgt + c * 3 * COUT + o0;
 #pragma unroll
             for (int oo = 0; oo < OG; ++oo) {
                 if (o0 + oo < COUT) {
@@ -162,13 +161,13 @@ __global__ __launch_bounds__(kCellThreads) void cell_kernel(CellDev cd, const fl
         for (int i = tid; i < tt * F; i += kCellThreads) sx[i] = x[(b * T + t0) * F + i];
         __syncthreads();
         // ---- encoder, batched over the chunk (gruunet2.py:136-144)
-        conv_down<1, kHidden, 5>(cd.w_down[0], cd.bt_down[0], sx, sd0, 8 * C, tt, wv, lane);
+        conv_down<1, kHidden, 5>((cfloat_ptr)cd.w_down[0], cd.bt_down[0], sx, sd0, 8 * C, tt, wv, lane);
         __syncthreads();
-        conv_down<kHidden, kHidden, 5>(cd.w_down[1], cd.bt_down[1], sd0, sd1, 4 * C, tt, wv, lane);
+        conv_down<kHidden, kHidden, 5>((cfloat_ptr)cd.w_down[1], cd.bt_down[1], sd0, sd1, 4 * C, tt, wv, lane);
         __syncthreads();
-        conv_down<kHidden, kHidden, 5>(cd.w_down[2], cd.bt_down[2], sd1, sd2, 2 * C, tt, wv, lane);
+        conv_down<kHidden, kHidden, 5>((cfloat_ptr)cd.w_down[2], cd.bt_down[2], sd1, sd2, 2 * C, tt, wv, lane);
         __syncthreads();
-        conv_down<kHidden, kGates, 13>(cd.w_down[3], cd.bt_down[3], sd2, sd3, C, tt, wv, lane);
+        conv_down<kHidden, kGates, 13>((cfloat_ptr)cd.w_down[3], cd.bt_down[3], sd2, sd3, C, tt, wv, lane);
         __syncthreads();
         // ---- recurrent part, sequential in t (gruunet2.py:232-240)
         for (int t = 0; t < tt; ++t) {
@@ -199,16 +198,16 @@ __global__ __launch_bounds__(kCellThreads) void cell_kernel(CellDev cd, const fl
             __syncthreads();
         }
         // ---- decoder, batched over the chunk (gruunet2.py:184-199); skips are d2, d1, d0, (x unused: last has no cat)
-        conv_up<kHidden, 0, kHidden, 5, false>(cd.w_up[0], cd.bt_up[0], shi, nullptr, su0, C, tt, wv, lane, (size_t)kHidden * 2 * C);
+        conv_up<kHidden, 0, kHidden, 5, false>((cfloat_ptr)cd.w_up[0], cd.bt_up[0], shi, nullptr, su0, C, tt, wv, lane, (size_t)kHidden * 2 * C);
         __syncthreads();
-        conv_up<kHidden, kHidden, kHidden, 5, false>(cd.w_up[1], cd.bt_up[1], su0, sd2, su1, 2 * C, tt, wv, lane, (size_t)kHidden * 4 * C);
+        conv_up<kHidden, kHidden, kHidden, 5, false>((cfloat_ptr)cd.w_up[1], cd.bt_up[1], su0, sd2, su1, 2 * C, tt, wv, lane, (size_t)kHidden * 4 * C);
         __syncthreads();
-        conv_up<kHidden, kHidden, kHidden, 5, false>(cd.w_up[2], cd.bt_up[2], su1, sd1, su2, 4 * C, tt, wv, lane, (size_t)kHidden * 8 * C);
+        conv_up<kHidden, kHidden, kHidden, 5, false>((cfloat_ptr)cd.w_up[2], cd.bt_up[2], su1, sd1, su2, 4 * C, tt, wv, lane, (size_t)kHidden * 8 * C);
         __syncthreads();
         // last level: one output channel; spread (t, position) over all four waves
         {
             const int l = 8 * C, items = tt * l;
-            const float* wgt = cd.w_up[3];
+            cfloat_ptr wgt = (cfloat_ptr)cd.w_up[3];
             for (int it = tid; it < items; it += kCellThreads) {
                 const int t = it / l, i = it - t * l;
                 float ev = cd.bt_up[3][2 * i], od = cd.bt_up[3][2 * i + 1];

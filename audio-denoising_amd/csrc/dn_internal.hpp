@@ -6,7 +6,16 @@
 #include "../../include/dn_denoise.h"
 #include "dn_plan.hpp"
 
+// Wave-uniform read-only tables (conv weights) are read through the constant address space so that
+// hipcc emits scalar loads (s_load_dwordx*, scalar cache) and the FMAs take the weight as an SGPR
+// operand, instead of 64 lanes fetching the same dword through the vector memory path.
+#ifndef DN_CONST_AS
+#define DN_CONST_AS __attribute__((address_space(4)))
+#endif
+
 namespace dn {
+
+typedef const DN_CONST_AS float* cfloat_ptr;
 
 constexpr int kNfft = 1024;     // n_fft the FFT kernels are built for (hop = 512)
 constexpr int kHidden = 17;      // H

@@ -28,6 +28,7 @@
 #define __forceinline__ inline
 #define __shared__ static
 #define __launch_bounds__(...)
+#define DN_CONST_AS
 
 struct float2 { float x, y; };
 struct float4 { float x, y, z, w; };
