@@ -252,12 +252,18 @@ int dn_model_create(const float* weights, size_t n_floats, const dn_model_cfg* c
     m->cfg = *cfg;
     m->w.assign(weights, weights + n_floats);
     const float* W = m->w.data();
-    for (int l = 0; l < 4; ++l) {   // Conv1d weight (Cout, Ct, 3) -> [c][k][o], data channels c < Cd
+    // MFMA A fragments (v_mfma_f32_16x16x4_f32): lane l of k-step ks supplies W[o = 16 mt + (l & 15)][K slot 4 ks + (l >> 4)].
+    for (int l = 0; l < 4; ++l) {   // Conv1d weight (Cout, Ct, 3): K order tap-major, channels in fours -> [mt][ks][64]
         const int cd = l == 0 ? 1 : 17, ct = cd + 6, co = l == 3 ? 51 : 17;
-        std::vector<float> p((size_t)cd * 3 * co);
-        for (int c = 0; c < cd; ++c)
-            for (int k = 0; k < 3; ++k)
-                for (int o = 0; o < co; ++o) p[((size_t)c * 3 + k) * co + o] = W[sl.dw[l] + ((size_t)o * ct + c) * 3 + k];
+        const int cs = (cd + 3) / 4, ks_n = cd == 1 ? 1 : 3 * cs, mtiles = (co + 15) / 16;
+        std::vector<float> p((size_t)mtiles * ks_n * 64, 0.0f);
+        for (int mt = 0; mt < mtiles; ++mt)
+            for (int ks = 0; ks < ks_n; ++ks)
+                for (int ln = 0; ln < 64; ++ln) {
+                    const int o = mt * 16 + (ln & 15), q = ln >> 4;
+                    const int tap = cd == 1 ? q : ks / cs, c = cd == 1 ? 0 : 4 * (ks % cs) + q;
+                    if (o < co && tap < 3 && c < cd) p[((size_t)mt * ks_n + ks) * 64 + ln] = W[sl.dw[l] + ((size_t)o * ct + c) * 3 + tap];
+                }
         m->off_down[l] = m->packed.add(p.data(), p.size() * sizeof(float));
     }
     {
@@ -267,13 +273,25 @@ int dn_model_create(const float* weights, size_t n_floats, const dn_model_cfg* c
                 for (int o = 0; o < 51; ++o) p[((size_t)c * 3 + k) * 51 + o] = W[sl.gw + ((size_t)o * 23 + c) * 3 + k];
         m->off_gh = m->packed.add(p.data(), p.size() * sizeof(float));
     }
-    for (int l = 0; l < 4; ++l) {   // ConvTranspose1d weight (Ct, Cout, 3) -> [c][k][o]
-        const int cd = l == 0 ? 17 : 34, co = l == 3 ? 1 : 17;
-        std::vector<float> p((size_t)cd * 3 * co);
-        for (int c = 0; c < cd; ++c)
-            for (int k = 0; k < 3; ++k)
-                for (int o = 0; o < co; ++o) p[((size_t)c * 3 + k) * co + o] = W[sl.uw[l] + ((size_t)c * co + o) * 3 + k];
+    for (int l = 0; l < 3; ++l) {   // ConvTranspose1d weight (Ct, Cout, 3) -> [mt][tap set: k=1,k=2,k=0][ks][64], parts of 17 channels in fours
+        const int parts = l == 0 ? 1 : 2, co = 17, ksu = parts * 5;
+        static const int kTapOfSet[3] = {1, 2, 0};
+        std::vector<float> p((size_t)2 * 3 * ksu * 64, 0.0f);
+        for (int mt = 0; mt < 2; ++mt)
+            for (int set = 0; set < 3; ++set)
+                for (int ks = 0; ks < ksu; ++ks)
+                    for (int ln = 0; ln < 64; ++ln) {
+                        const int o = mt * 16 + (ln & 15), q = ln >> 4, cp = 4 * (ks % 5) + q, c = (ks / 5) * 17 + cp;
+                        if (o < co && cp < 17)
+                            p[(((size_t)mt * 3 + set) * ksu + ks) * 64 + ln] = W[sl.uw[l] + ((size_t)c * co + o) * 3 + kTapOfSet[set]];
+                    }
         m->off_up[l] = m->packed.add(p.data(), p.size() * sizeof(float));
+    }
+    {   // last decoder level (one output channel): [c][k], read through the scalar cache
+        std::vector<float> p((size_t)34 * 3);
+        for (int c = 0; c < 34; ++c)
+            for (int k = 0; k < 3; ++k) p[(size_t)c * 3 + k] = W[sl.uw[3] + (size_t)c * 3 + k];
+        m->off_up[3] = m->packed.add(p.data(), p.size() * sizeof(float));
     }
     hipError_t e = m->packed.upload();
     if (e != hipSuccess) { m->packed.release(); delete m; return fail(DN_ERR_HIP, std::string("weight upload: ") + hipGetErrorString(e)); }

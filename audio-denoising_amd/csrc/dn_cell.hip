@@ -6,100 +6,153 @@
 // The reference issues ~60 small tensor ops per time step.  Here ONE workgroup owns ONE stream
 // and runs the whole forward out of LDS (activations of kCellChunk = 3 steps: ~34 KB at F = 80):
 //   * the encoder does not depend on hx (gruunet2.py:231), so it runs batched over the chunk's
-//     time steps; likewise the decoder after the recurrent part;
-//   * only  gh = relu(conv(hx)), the GRU gates and h' are sequential in t;
+//     time steps; likewise the decoder after the recurrent part; only gh = relu(conv(hx)), the
+//     GRU gates and h' are sequential in t;
 //   * the 6 Gaussian position-code channels are input independent: their convolution is folded
 //     into per-position bias tables at plan time (CellDev::bt_*), so kernels convolve data
 //     channels only (-26 % MACs);
-//   * encoder/decoder: lane = (t, position), wavefront = group of output channels, so every
-//     weight is wave-uniform and comes through the scalar cache while activations are
-//     stride-1 LDS reads;  bottleneck (51 gate channels x C positions): lane = (position,
-//     gate channel) with that lane's 51 recurrent weights pinned in VGPRs across time steps.
+//   * every conv level is a small dense contraction  out[o][(t,p)] = sum_(c,tap) W[o][(c,tap)] *
+//     im2col(x)[(c,tap)][(t,p)]  and runs on the matrix cores with v_mfma_f32_16x16x4_f32
+//     (f32 in, f32 accumulate: bit-for-bit an fmaf chain, so the fp32 parity bar holds):
+//     rows = 16 output channels, columns = 16 (t, position) items, K = 4 (channel, tap) pairs
+//     per instruction.  The A (weight) fragments are pre-arranged on the host in lane order
+//     ([m-tile][k-step][64 lanes], one coalesced 256-B load each); the B fragments are the
+//     im2col view of the LDS activations -- one ds_read_b32 per lane per k-step at a computed
+//     address, no staging copy.  1,024 MACs per instruction instead of 64: the per-stream
+//     forward is latency-bound on instruction issue, so this is what shortens it;
+//   * bottleneck hidden gates (51 channels x C positions, N too small for a tile): lane =
+//     (gate channel, position) on the VALU with that lane's 51 recurrent weights pinned in VGPRs
+//     across time steps; the single-channel last decoder level: lane = (t, position), VALU.
 #include "dn_internal.hpp"
 
 namespace dn {
 
 constexpr int kCellThreads = 256;
+constexpr int kCellWaves = kCellThreads / 64;
 
-// ---- Conv1d k3 s2 p1 + folded position bias + relu.  in [TT][CIN][2*LOUT] -> out [TT][COUT][LOUT]
-// OG = output channels per wavefront.
-template <int CIN, int COUT, int OG>
-__device__ __forceinline__ void conv_down(cfloat_ptr wgt, const float* __restrict__ bt,
-                                          const float* in, float* out, int lout, int tt, int wv, int lane) {
-    const int lin = 2 * lout;
-    const int o0 = wv * OG;
-    if (o0 >= COUT) return;
-    const int items = tt * lout;
-    for (int it = lane; it < items; it += 64) {
-        const int t = it / lout, j = it - t * lout;
-        float acc[OG];
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// ---- Conv1d k3 s2 p1 (+ folded position bias, relu) as an MFMA contraction.
+//   in [TT][CIN][2*lout] (LDS) -> out [TT][COUT][lout] (LDS)
+//   afrag: [MTILES][KS][64] weight fragments, K order = tap-major, channels in groups of 4
+//          (CIN = 1: one k-step whose 4 K slots are the 3 taps + a zero)
+//   work split: tile = (n-tile of 16 items) x (group of MT m-tiles); tiles are dealt to waves round robin.
+template <int CIN, int COUT, int MT>
+__device__ __forceinline__ void mconv_down(const float* __restrict__ afrag, const float* __restrict__ bt, const float* in,
+                                           float* out, int lout, int tt, int wv, int lane) {
+    constexpr int CS = (CIN + 3) / 4;
+    constexpr int KS = CIN == 1 ? 1 : 3 * CS;
+    constexpr int MTILES = (COUT + 15) / 16;
+    constexpr int MG = MTILES / MT;
+    const int lin = 2 * lout, items = tt * lout, ntiles = (items + 15) >> 4;
+    const int q = lane >> 4, jl = lane & 15;
+    for (int tile = wv; tile < ntiles * MG; tile += kCellWaves) {
+        const int nt = tile % ntiles, mt0 = (tile / ntiles) * MT;
+        const int item = nt * 16 + jl;
+        const bool valid = item < items;
+        const int itc = valid ? item : 0;
+        const int t = itc / lout, p = itc - t * lout;
+        f32x4 acc[MT];
 #pragma unroll
-        for (int oo = 0; oo < OG; ++oo) acc[oo] = (o0 + oo < COUT) ? bt[(o0 + oo) * lout + j] : 0.0f;
-        const float* xin = in + (size_t)t * CIN * lin + 2 * j;
-        for (int c = 0; c < CIN; ++c) {
-            const float x0 = j > 0 ? xin[c * lin - 1] : 0.0f;
-            const float x1 = xin[c * lin];
-            const float x2 = xin[c * lin + 1];
-            cfloat_ptr wc = wgt + c * 3 * COUT + o0;
+        for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-            for (int oo = 0; oo < OG; ++oo) {
-                if (o0 + oo < COUT) {
-                    acc[oo] = fmaf(wc[oo], x0, acc[oo]);
-                    acc[oo] = fmaf(wc[COUT + oo], x1, acc[oo]);
-                    acc[oo] = fmaf(wc[2 * COUT + oo], x2, acc[oo]);
-                }
+            for (int r = 0; r < 4; ++r) {
+                const int o = (mt0 + mi) * 16 + q * 4 + r;
+                acc[mi][r] = o < COUT ? bt[o * lout + p] : 0.0f;
             }
-        }
+        const float* af = afrag + (size_t)mt0 * KS * 64 + lane;
+        if (CIN == 1) {
+            const int idx = t * lin + 2 * p - 1 + q;
+            const bool ok = q < 3 && !(q == 0 && p == 0);
+            const float b = ok ? in[idx] : 0.0f;
 #pragma unroll
-        for (int oo = 0; oo < OG; ++oo)
-            if (o0 + oo < COUT) out[((size_t)t * COUT + o0 + oo) * lout + j] = fmaxf(acc[oo], 0.0f);
+            for (int mi = 0; mi < MT; ++mi) acc[mi] = mfma16(af[mi * KS * 64], b, acc[mi]);
+        } else {
+            const float* base = in + (size_t)t * CIN * lin + 2 * p - 1;
+#pragma unroll
+            for (int tap = 0; tap < 3; ++tap)
+#pragma unroll
+                for (int cs = 0; cs < CS; ++cs) {
+                    const int c = min(4 * cs + q, CIN - 1);          // padded K slots carry zero weights
+                    float b = base[c * lin + tap];
+                    if (tap == 0 && p == 0) b = 0.0f;                // left zero padding of the conv
+                    const int ks = tap * CS + cs;
+#pragma unroll
+                    for (int mi = 0; mi < MT; ++mi) acc[mi] = mfma16(af[(mi * KS + ks) * 64], b, acc[mi]);
+                }
+        }
+        if (valid) {
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = (mt0 + mi) * 16 + q * 4 + r;
+                    if (o < COUT) out[((size_t)t * COUT + o) * lout + p] = fmaxf(acc[mi][r], 0.0f);
+                }
+        }
     }
 }
 
-// ---- ConvTranspose1d k3 s2 p1 output_padding 1 (L -> 2L) on cat(a, skip) data channels + folded
-// position bias.  a [TT][CA][L], skip [TT][CS][L] (CS may be 0) -> out [TT][COUT][2L], relu unless LAST.
-// Lane = (t, input position i) produces outputs 2i (tap k=1 of x[i]) and 2i+1 (k=2 of x[i], k=0 of x[i+1]).
-template <int CA, int CS, int COUT, int OG, bool LAST>
-__device__ __forceinline__ void conv_up(cfloat_ptr wgt, const float* __restrict__ bt, const float* a,
-                                        const float* skip, float* out, int l, int tt, int wv, int lane,
-                                        size_t out_t_stride) {
-    const int o0 = wv * OG;
-    if (o0 >= COUT) return;
-    const int items = tt * l;
-    const int lo = 2 * l;
-    for (int it = lane; it < items; it += 64) {
-        const int t = it / l, i = it - t * l;
-        float ev[OG], od[OG];
-#pragma unroll
-        for (int oo = 0; oo < OG; ++oo) {
-            const bool ok = o0 + oo < COUT;
-            ev[oo] = ok ? bt[(o0 + oo) * lo + 2 * i] : 0.0f;
-            od[oo] = ok ? bt[(o0 + oo) * lo + 2 * i + 1] : 0.0f;
-        }
+// ---- ConvTranspose1d k3 s2 p1 output_padding 1 (L -> 2L) on cat(a, skip) data channels (+ folded position
+// bias, relu).  a [TT][17][l], skip [TT][17][l] (absent at the first level) -> out [TT][17][2l].
+// Item = (t, input position i):  out[2i]   = sum_c w[c][o][1] x[c][i]
+//                                out[2i+1] = sum_c w[c][o][2] x[c][i] + w[c][o][0] x[c][i+1]
+// afrag: [MTILES=2][3 tap sets: k=1, k=2, k=0][KSU][64]; K order = part-major (a, then skip), channels in fours.
+template <bool SKIP, int MT>
+__device__ __forceinline__ void mconv_up(const float* __restrict__ afrag, const float* __restrict__ bt, const float* a,
+                                         const float* skip, float* out, int l, int tt, int wv, int lane) {
+    constexpr int CS = 5;                      // ceil(17 / 4)
+    constexpr int KSU = SKIP ? 2 * CS : CS;
+    constexpr int MTILES = 2, MG = MTILES / MT;
+    const int lo = 2 * l, items = tt * l, ntiles = (items + 15) >> 4;
+    const int q = lane >> 4, jl = lane & 15;
+    for (int tile = wv; tile < ntiles * MG; tile += kCellWaves) {
+        const int nt = tile % ntiles, mt0 = (tile / ntiles) * MT;
+        const int item = nt * 16 + jl;
+        const bool valid = item < items;
+        const int itc = valid ? item : 0;
+        const int t = itc / l, i = itc - t * l;
         const bool has_next = i + 1 < l;
-        for (int c = 0; c < CA + CS; ++c) {
-            const float* src = c < CA ? a + ((size_t)t * CA + c) * l : skip + ((size_t)t * CS + (c - CA)) * l;
-            const float x0 = src[i];
-            const float x1 = has_next ? src[i + 1] : 0.0f;
-            cfloat_ptr wc = wgt + c * 3 * COUT + o0;
+        f32x4 ev[MT], od[MT];
 #pragma unroll
-            for (int oo = 0; oo < OG; ++oo) {
-                if (o0 + oo < COUT) {
-                    ev[oo] = fmaf(wc[COUT + oo], x0, ev[oo]);
-                    od[oo] = fmaf(wc[2 * COUT + oo], x0, od[oo]);
-                    od[oo] = fmaf(wc[oo], x1, od[oo]);
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = (mt0 + mi) * 16 + q * 4 + r;
+                ev[mi][r] = o < kHidden ? bt[o * lo + 2 * i] : 0.0f;
+                od[mi][r] = o < kHidden ? bt[o * lo + 2 * i + 1] : 0.0f;
+            }
+        const float* af = afrag + (size_t)mt0 * 3 * KSU * 64 + lane;
+#pragma unroll
+        for (int part = 0; part < (SKIP ? 2 : 1); ++part) {
+            const float* src = (part == 0 ? a : skip) + (size_t)t * kHidden * l + i;
+#pragma unroll
+            for (int cs = 0; cs < CS; ++cs) {
+                const int c = min(4 * cs + q, kHidden - 1);
+                const float x0 = src[c * l];
+                const float x1 = has_next ? src[c * l + 1] : 0.0f;
+                const int ks = part * CS + cs;
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi) {
+                    const float* am = af + (size_t)mi * 3 * KSU * 64;
+                    ev[mi] = mfma16(am[(0 * KSU + ks) * 64], x0, ev[mi]);
+                    od[mi] = mfma16(am[(1 * KSU + ks) * 64], x0, od[mi]);
+                    od[mi] = mfma16(am[(2 * KSU + ks) * 64], x1, od[mi]);
                 }
             }
         }
+        if (valid) {
 #pragma unroll
-        for (int oo = 0; oo < OG; ++oo) {
-            if (o0 + oo < COUT) {
-                float e = ev[oo], o = od[oo];
-                if (!LAST) { e = fmaxf(e, 0.0f); o = fmaxf(o, 0.0f); }
-                float* dst = out + (size_t)t * out_t_stride + (size_t)(o0 + oo) * lo + 2 * i;
-                dst[0] = e;
-                dst[1] = o;
-            }
+            for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = (mt0 + mi) * 16 + q * 4 + r;
+                    if (o < kHidden)
+                        *reinterpret_cast<float2*>(out + ((size_t)t * kHidden + o) * lo + 2 * i) =
+                            make_float2(fmaxf(ev[mi][r], 0.0f), fmaxf(od[mi][r], 0.0f));
+                }
         }
     }
 }
@@ -111,7 +164,7 @@ struct CellLds {
     int x, d0, d1, d2, d3, h, gh, hi, u0, u1, u2, total;
     __host__ __device__ explicit CellLds(int C) {
         const int T = kCellChunk, F = 16 * C;
-        int o = 0;
+        int o = 4;                            // words 0..3: guard in front of the first buffer (index -1 reads)
         x = o;  o += T * F;
         d0 = o; o += T * kHidden * 8 * C;
         d1 = o; o += T * kHidden * 4 * C;
@@ -127,7 +180,7 @@ struct CellLds {
     }
 };
 
-constexpr int kCellLdsFloats = 3 * 16 * kMaxC + 3 * 17 * 14 * kMaxC * 2 + 3 * 51 * kMaxC + 17 * kMaxC + 51 * kMaxC + 3 * 17 * kMaxC;
+constexpr int kCellLdsFloats = 4 + 3 * 16 * kMaxC + 3 * 17 * 14 * kMaxC * 2 + 3 * 51 * kMaxC + 17 * kMaxC + 51 * kMaxC + 3 * 17 * kMaxC;
 
 __global__ __launch_bounds__(kCellThreads) void cell_kernel(CellDev cd, const float* __restrict__ x,
                                                             const float* __restrict__ hx_in, float* __restrict__ out,
@@ -143,6 +196,7 @@ __global__ __launch_bounds__(kCellThreads) void cell_kernel(CellDev cd, const fl
     float* sd3 = lds + L.d3; float* sh = lds + L.h;   float* sgh = lds + L.gh; float* shi = lds + L.hi;
     float* su0 = lds + L.u0; float* su1 = lds + L.u1; float* su2 = lds + L.u2;
 
+    if (tid < 4) lds[tid] = 0.0f;
     // hidden state -> LDS (gruunet2.py:294-301: zeros when the caller passes none)
     for (int i = tid; i < kHidden * C; i += kCellThreads) sh[i] = hx_in != nullptr ? hx_in[b * kHidden * C + i] : 0.0f;
 
@@ -161,13 +215,13 @@ __global__ __launch_bounds__(kCellThreads) void cell_kernel(CellDev cd, const fl
         for (int i = tid; i < tt * F; i += kCellThreads) sx[i] = x[(b * T + t0) * F + i];
         __syncthreads();
         // ---- encoder, batched over the chunk (gruunet2.py:136-144)
-        conv_down<1, kHidden, 5>((cfloat_ptr)cd.w_down[0], cd.bt_down[0], sx, sd0, 8 * C, tt, wv, lane);
+        mconv_down<1, kHidden, 2>(cd.w_down[0], cd.bt_down[0], sx, sd0, 8 * C, tt, wv, lane);
         __syncthreads();
-        conv_down<kHidden, kHidden, 5>((cfloat_ptr)cd.w_down[1], cd.bt_down[1], sd0, sd1, 4 * C, tt, wv, lane);
+        mconv_down<kHidden, kHidden, 2>(cd.w_down[1], cd.bt_down[1], sd0, sd1, 4 * C, tt, wv, lane);
         __syncthreads();
-        conv_down<kHidden, kHidden, 5>((cfloat_ptr)cd.w_down[2], cd.bt_down[2], sd1, sd2, 2 * C, tt, wv, lane);
+        mconv_down<kHidden, kHidden, 1>(cd.w_down[2], cd.bt_down[2], sd1, sd2, 2 * C, tt, wv, lane);
         __syncthreads();
-        conv_down<kHidden, kGates, 13>((cfloat_ptr)cd.w_down[3], cd.bt_down[3], sd2, sd3, C, tt, wv, lane);
+        mconv_down<kHidden, kGates, 1>(cd.w_down[3], cd.bt_down[3], sd2, sd3, C, tt, wv, lane);
         __syncthreads();
         // ---- recurrent part, sequential in t (gruunet2.py:232-240)
         for (int t = 0; t < tt; ++t) {
@@ -197,14 +251,14 @@ __global__ __launch_bounds__(kCellThreads) void cell_kernel(CellDev cd, const fl
             }
             __syncthreads();
         }
-        // ---- decoder, batched over the chunk (gruunet2.py:184-199); skips are d2, d1, d0, (x unused: last has no cat)
-        conv_up<kHidden, 0, kHidden, 5, false>((cfloat_ptr)cd.w_up[0], cd.bt_up[0], shi, nullptr, su0, C, tt, wv, lane, (size_t)kHidden * 2 * C);
+        // ---- decoder, batched over the chunk (gruunet2.py:184-199); skips are d2, d1, d0 (the last level has no cat)
+        mconv_up<false, 1>(cd.w_up[0], cd.bt_up[0], shi, nullptr, su0, C, tt, wv, lane);
         __syncthreads();
-        conv_up<kHidden, kHidden, kHidden, 5, false>((cfloat_ptr)cd.w_up[1], cd.bt_up[1], su0, sd2, su1, 2 * C, tt, wv, lane, (size_t)kHidden * 4 * C);
+        mconv_up<true, 1>(cd.w_up[1], cd.bt_up[1], su0, sd2, su1, 2 * C, tt, wv, lane);
         __syncthreads();
-        conv_up<kHidden, kHidden, kHidden, 5, false>((cfloat_ptr)cd.w_up[2], cd.bt_up[2], su1, sd1, su2, 4 * C, tt, wv, lane, (size_t)kHidden * 8 * C);
+        mconv_up<true, 2>(cd.w_up[2], cd.bt_up[2], su1, sd1, su2, 4 * C, tt, wv, lane);
         __syncthreads();
-        // last level: one output channel; spread (t, position) over all four waves
+        // last level: one output channel; lane = (t, input position), weights through the scalar cache
         {
             const int l = 8 * C, items = tt * l;
             cfloat_ptr wgt = (cfloat_ptr)cd.w_up[3];
@@ -212,6 +266,7 @@ __global__ __launch_bounds__(kCellThreads) void cell_kernel(CellDev cd, const fl
                 const int t = it / l, i = it - t * l;
                 float ev = cd.bt_up[3][2 * i], od = cd.bt_up[3][2 * i + 1];
                 const bool has_next = i + 1 < l;
+#pragma unroll 2
                 for (int c = 0; c < 2 * kHidden; ++c) {
                     const float* src = c < kHidden ? su2 + ((size_t)t * kHidden + c) * l
                                                    : sd0 + ((size_t)t * kHidden + (c - kHidden)) * l;

@@ -17,6 +17,12 @@ namespace dn {
 
 typedef const DN_CONST_AS float* cfloat_ptr;
 
+// accumulator fragment of v_mfma_f32_16x16x4_f32: lane l holds D[row = (l >> 4) * 4 + r][col = l & 15], r = 0..3
+#ifndef DN_F32X4
+#define DN_F32X4
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#endif
+
 constexpr int kNfft = 1024;     // n_fft the FFT kernels are built for (hop = 512)
 constexpr int kHidden = 17;      // H
 constexpr int kGates = 51;       // 3H

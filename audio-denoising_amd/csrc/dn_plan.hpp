@@ -24,9 +24,13 @@ struct DspDev {
 // Packed GRUUNet2 weights (data channels only; the position-code channels are folded into
 // the per-position bias tables `bt_*`, which depend on the number of compressed bins C).
 struct CellDev {
-    const float* w_down[4];  // [Cd][3][Cout]   Cd = 1,17,17,17   Cout = 17,17,17,51
-    const float* w_gh;       // [17][3][51]
-    const float* w_up[4];    // [Cd][3][Cout]   Cd = 17,34,34,34  Cout = 17,17,17,1
+    // Encoder / decoder weights are stored as v_mfma_f32_16x16x4_f32 A fragments in lane order (dn_cell.hip):
+    //   w_down[l]: [m-tile][k-step][64]          K = taps x channels-in-fours (level 0: the 3 taps)
+    //   w_up[l<3]: [m-tile][tap set][k-step][64]  tap sets k=1 (even outputs), k=2 and k=0 (odd outputs)
+    //   w_up[3]  : [34][3] plain (single output channel, VALU)
+    const float* w_down[4];  // data channels 1,17,17,17 -> 17,17,17,51
+    const float* w_gh;       // [17][3][51]  (per-lane, pinned in VGPRs)
+    const float* w_up[4];    // data channels 17,34,34,34 -> 17,17,17,1
     const float* bt_down[4]; // [Cout][Lout]    Lout = 8C,4C,2C,C
     const float* bt_gh;      // [51][C]
     const float* bt_up[4];   // [Cout][Lout]    Lout = 2C,4C,8C,16C

@@ -117,3 +117,27 @@ inline float __shfl_xor(float v, int mask) { return dn_emu::shfl(v, (int)(dn_emu
 inline float __shfl(float v, int src) { return dn_emu::shfl(v, src); }
 using std::max;
 using std::min;
+
+// v_mfma_f32_16x16x4_f32 emulated as a wave-collective op: D = A(16x4) B(4x16) + C with
+// lane l supplying A[l & 15][l >> 4], B[l >> 4][l & 15] and holding D[(l >> 4) * 4 + r][l & 15].
+#define DN_F32X4
+typedef float f32x4 __attribute__((vector_size(16)));
+inline f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, f32x4 c, int, int, int) {
+    using namespace dn_emu;
+    const int l = tIdx.x & 63;
+    static std::vector<std::vector<float>> pool(16, std::vector<float>(128));   // [wave of the block][A | B]
+    float* s = pool[tIdx.x / 64].data();
+    s[l] = a;
+    s[64 + l] = b;
+    ctx.wave->wait();
+    const int col = l & 15, q = l >> 4;
+    f32x4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        const int row = q * 4 + r;
+        float acc = c[r];
+        for (int k = 0; k < 4; ++k) acc = std::fmaf(s[k * 16 + row], s[64 + k * 16 + col], acc);
+        d[r] = acc;
+    }
+    ctx.wave->wait();
+    return d;
+}

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Profiling driver: a few fused hops at batch 256 (same workload as bench.py), nothing else.
+Run under rocprofv3 (--kernel-trace --stats, or a --pmc pass) from the repo root."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+
+def main():
+    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    batch = int(sys.argv[2]) if len(sys.argv) > 2 else bench.BATCH
+    dev = torch.device("cuda", 0)
+    dn = bench.build_denoiser(dev)
+    g = torch.Generator().manual_seed(1234)
+    frames = (0.1 * torch.randn(batch, bench.N_FFT, generator=g)).to(dev)
+    hx = dn.init_hx(batch)
+    out = torch.empty_like(frames)
+    for i in range(steps):
+        dn.process_frame_(frames, hx, out, seed=1000 + i, stream_id0=0)
+    torch.cuda.synchronize()
+    print("ok", float(out.abs().mean()))
+
+
+if __name__ == "__main__":
+    main()
