@@ -5,8 +5,9 @@
 // The reference runs 32 x {istft, stft, phase update} as ~65 separate passes over
 // (B,513,3) complex tensors.  Here a workgroup of three wavefronts (one per STFT column) keeps
 // the whole problem on chip for all iterations:
-//   registers : per lane 8 bins (+Nyquist) of magnitude, current phase estimate and previous
-//               rebuilt spectrum, the FFT twiddles and the folded window constants
+//   registers : per lane 4 bin PAIRS (k, 512-k) of magnitude, current phase estimate and previous
+//               rebuilt spectrum (the Hermitian split/merge of the real FFT is then lane-local),
+//               the FFT twiddles and the folded window constants
 //   LDS       : one 576-entry complex exchange tile per wave, and a ping-pong pair of
 //               overlap-add lines (the 2*n_fft padded signal collapses to two n_fft lines
 //               because only the centre n_fft samples survive the istft trim)
@@ -57,17 +58,18 @@ __global__ __launch_bounds__(kGlThreads) void griffinlim_kernel(DspDev d, const 
     FftTwiddles tw;
     load_twiddles(tw, d.tw512, lane);
 
-    // lane constants: bin twiddles, synthesis window / 512, analysis window * 1/envelope and
-    // the source sample indices of this column in the rebuilt signal s[0..1024):
+    // lane constants: bin twiddles of the owned pairs, synthesis window / 512, analysis window * 1/envelope
+    // and the source sample indices of this column in the rebuilt signal s[0..1024):
     //   column 0: n < 512 -> s[512-n] (reflection), else s[n-512]
     //   column 1: s[n]
     //   column 2: n < 512 -> s[n+512], else s[1534-n] (reflection)
-    float2 wk[8], wsyn[8], cw[8];
+    float2 wk[4], wsyn[8], cw[8];
     int src0[8], src1[8];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) wk[t] = d.tw1024[lane + 64 * t];
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
         const int m = lane + 64 * t;
-        wk[t] = d.tw1024[m];
         const float2 ww = reinterpret_cast<const float2*>(d.window)[m];
         wsyn[t] = make_float2(ww.x * (1.0f / 512.0f), ww.y * (1.0f / 512.0f));
         const int n0 = 2 * m, n1 = n0 + 1;
@@ -79,29 +81,45 @@ __global__ __launch_bounds__(kGlThreads) void griffinlim_kernel(DspDev d, const 
         cw[t] = make_float2(ww.x * d.inv_env[i0], ww.y * d.inv_env[i1]);
     }
 
-    // per-lane state: 8 bins k = lane + 64 t, plus the Nyquist bin (meaningful in lane 0)
-    float mg[8], mgn;
-    float2 ang[8], tprev[8];
-    float angn_re, tprevn = 0.0f;
+    // per-lane state: the 4 bin pairs (k, 512-k), k = lane + 64 t, plus bin 256 (meaningful in lane 0)
+    float mlo[4], mhi[4], mmid;
+    float2 alo[4], ahi[4], amid, plo[4], phi[4], pmid;
     {
         const size_t row = (b * 3 + w) * kBins;
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const int k = lane + 64 * t;
-            mg[t] = mag != nullptr ? mag[row + k] : 1.0f;
-            ang[t] = init != nullptr ? init[row + k] : rand_angle(seed, sid0 + b, w, k);
-            tprev[t] = make_float2(0.0f, 0.0f);
+        for (int t = 0; t < 4; ++t) {
+            const int k = lane + 64 * t, kh = 512 - k;
+            mlo[t] = mag != nullptr ? mag[row + k] : 1.0f;
+            mhi[t] = mag != nullptr ? mag[row + kh] : 1.0f;
+            alo[t] = init != nullptr ? init[row + k] : rand_angle(seed, sid0 + b, w, k);
+            ahi[t] = init != nullptr ? init[row + kh] : rand_angle(seed, sid0 + b, w, kh);
+            plo[t] = make_float2(0.0f, 0.0f);
+            phi[t] = make_float2(0.0f, 0.0f);
         }
-        mgn = mag != nullptr ? mag[row + 512] : 1.0f;
-        angn_re = init != nullptr ? init[row + 512].x : rand_angle(seed, sid0 + b, w, 512).x;
+        mmid = mag != nullptr ? mag[row + 256] : 1.0f;
+        amid = init != nullptr ? init[row + 256] : rand_angle(seed, sid0 + b, w, 256);
+        pmid = make_float2(0.0f, 0.0f);
     }
 
-    float2 v[8];
+    // a = rebuilt - m * tprev; tprev = rebuilt; angles = a / (|a| + 1e-16)   (v_sqrt / v_rcp: 1 ulp)
+    auto update = [mom](float2 reb, float2& prev, float2& ang) {
+        const float ax = reb.x - mom * prev.x, ay = reb.y - mom * prev.y;
+        prev = reb;
+        const float inv = __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(fmaf(ax, ax, ay * ay)) + 1e-16f);
+        ang = make_float2(ax * inv, ay * inv);
+    };
+
+    float2 v[8], xlo[4], xhi[4], xmid;
     for (int it = 0;; ++it) {
-        // ---- istft of angles * magnitude: irfft per column, synthesis window, overlap-add lines
+        // ---- istft of angles * magnitude: Hermitian merge, inverse FFT, synthesis window, overlap-add lines
 #pragma unroll
-        for (int t = 0; t < 8; ++t) v[t] = make_float2(ang[t].x * mg[t], ang[t].y * mg[t]);
-        irfft1024(v, angn_re * mgn, tw, wk, mytile, mytile, lane);
+        for (int t = 0; t < 4; ++t) {
+            xlo[t] = make_float2(alo[t].x * mlo[t], alo[t].y * mlo[t]);
+            xhi[t] = make_float2(ahi[t].x * mhi[t], ahi[t].y * mhi[t]);
+        }
+        xmid = make_float2(amid.x * mmid, amid.y * mmid);
+        irfft_merge_pairs(xlo, xhi, xmid, wk, lane, v);
+        fft512<true>(v, tw, mytile, lane);
         float* y1 = ybuf[it & 1][0];
         float* yo = ybuf[it & 1][1];
 #pragma unroll
@@ -124,20 +142,15 @@ __global__ __launch_bounds__(kGlThreads) void griffinlim_kernel(DspDev d, const 
 #pragma unroll
         for (int t = 0; t < 8; ++t)
             v[t] = make_float2((y1[src0[t]] + yo[src0[t]]) * cw[t].x, (y1[src1[t]] + yo[src1[t]]) * cw[t].y);
-        const float rn = rfft1024(v, tw, wk, mytile, mytile, lane);
-        // ---- phase update with momentum: a = rebuilt - m*tprev; angles = a / (|a| + 1e-16)
+        fft512<false>(v, tw, mytile, lane);
+        rfft_split_pairs(v, wk, lane, xlo, xhi, xmid);
+        // ---- phase update with momentum
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const float ax = v[t].x - mom * tprev[t].x, ay = v[t].y - mom * tprev[t].y;
-            tprev[t] = v[t];
-            const float inv = 1.0f / (sqrtf(fmaf(ax, ax, ay * ay)) + 1e-16f);
-            ang[t] = make_float2(ax * inv, ay * inv);
+        for (int t = 0; t < 4; ++t) {
+            update(xlo[t], plo[t], alo[t]);
+            update(xhi[t], phi[t], ahi[t]);
         }
-        {
-            const float an = rn - mom * tprevn;
-            tprevn = rn;
-            angn_re = an / (fabsf(an) + 1e-16f);
-        }
+        update(xmid, pmid, amid);
     }
 }
 

@@ -178,4 +178,53 @@ __device__ __forceinline__ void irfft1024(float2 (&v)[8], float xnyq, const FftT
     fft512<true>(v, tw, tile, lane);
 }
 
+// ---- Pair-owned Hermitian split/merge (Griffin-Lim inner loop) ---------------------------------
+// Bins k and 512-k are produced together by the split, so the lane that owns k = lane + 64 t (t < 4)
+// also owns 512-k: the split, the per-bin phase update and the merge for the next inverse FFT are
+// then lane-local and only the FFT-order <-> pair-order hand-off crosses lanes.  That hand-off is
+// the fixed involution (lane j, reg t) <-> (lane 64-j, reg 7-t), done with ds_bpermute (no LDS
+// memory, no barrier).  Lane 0 pairs with itself: (0,512), (64,448), (128,384), (192,320) and the
+// self-paired bin 256.
+__device__ __forceinline__ float2 shfl2(float2 v, int src) { return make_float2(__shfl(v.x, src), __shfl(v.y, src)); }
+
+// Forward: v[t] = Z[lane + 64 t] (FFT512 of the packed real frame) ->
+//   lo[t] = X[k], hi[t] = X[512-k] for k = lane + 64 t, t = 0..3; mid = X[256] (meaningful in lane 0).
+__device__ __forceinline__ void rfft_split_pairs(const float2 (&v)[8], const float2 (&wk)[4], int lane,
+                                                 float2 (&lo)[4], float2 (&hi)[4], float2& mid) {
+    const int partner = (64 - lane) & 63;
+    float2 zp[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) zp[t] = shfl2(v[7 - t], partner);
+    if (lane == 0) { zp[0] = v[0]; zp[1] = v[7]; zp[2] = v[6]; zp[3] = v[5]; }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const float2 e = make_float2(0.5f * (v[t].x + zp[t].x), 0.5f * (v[t].y - zp[t].y));   // (Z + conj Zp)/2
+        const float2 d = make_float2(0.5f * (v[t].x - zp[t].x), 0.5f * (v[t].y + zp[t].y));   // (Z - conj Zp)/2
+        const float2 wd = cmul(wk[t], d);
+        lo[t] = make_float2(e.x + wd.y, e.y - wd.x);          // E - i wd
+        hi[t] = make_float2(e.x - wd.y, -(e.y + wd.x));       // conj(E + i wd)
+    }
+    mid = make_float2(v[4].x, -v[4].y);                        // X[256] = conj Z[256]
+}
+
+// Inverse: lo[t] = X[k], hi[t] = X[512-k], mid = X[256] -> v[t] = Z[lane + 64 t] ready for IFFT512
+// (Im X[0] and Im X[512] are ignored, as C2R transforms do).
+__device__ __forceinline__ void irfft_merge_pairs(float2 (&lo)[4], float2 (&hi)[4], float2 mid, const float2 (&wk)[4],
+                                                  int lane, float2 (&v)[8]) {
+    if (lane == 0) { lo[0].y = 0.0f; hi[0].y = 0.0f; }
+    float2 zh[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const float2 e = make_float2(0.5f * (lo[t].x + hi[t].x), 0.5f * (lo[t].y - hi[t].y));  // (X + conj Xp)/2
+        const float2 d = make_float2(0.5f * (lo[t].x - hi[t].x), 0.5f * (lo[t].y + hi[t].y));  // (X - conj Xp)/2
+        const float2 dd = cmul_conj(d, wk[t]);
+        v[t] = make_float2(e.x - dd.y, e.y + dd.x);           // E + i D
+        zh[t] = make_float2(e.x + dd.y, dd.x - e.y);          // conj(E) + i conj(D)
+    }
+    const int partner = (64 - lane) & 63;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) v[7 - t] = shfl2(zh[t], partner);
+    if (lane == 0) { v[7] = zh[1]; v[6] = zh[2]; v[5] = zh[3]; v[4] = make_float2(mid.x, -mid.y); }
+}
+
 }  // namespace dn
