@@ -36,24 +36,24 @@ __device__ __forceinline__ void philox4x32(uint32_t (&c)[4], uint32_t k0, uint32
 
 // real, imag ~ U[0,1) independently (torch.rand(dtype=complex64) semantics), keyed by
 // (seed, global stream id, column, bin) so sharding streams over GPUs does not change results.
-__device__ __forceinline__ float2 rand_angle(uint64_t seed, uint64_t sid, int col, int bin) {
+__device__ __forceinline__ v2f rand_angle(uint64_t seed, uint64_t sid, int col, int bin) {
     uint32_t c[4] = {(uint32_t)bin, (uint32_t)col, (uint32_t)sid, (uint32_t)(sid >> 32)};
     philox4x32(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-    return make_float2((float)(c[0] >> 8) * (1.0f / 16777216.0f), (float)(c[1] >> 8) * (1.0f / 16777216.0f));
+    return mk2((float)(c[0] >> 8) * (1.0f / 16777216.0f), (float)(c[1] >> 8) * (1.0f / 16777216.0f));
 }
 
 __global__ __launch_bounds__(kGlThreads) void griffinlim_kernel(DspDev d, const float* __restrict__ mag,
-                                                                const float2* __restrict__ init, uint64_t seed,
+                                                                const v2f* __restrict__ init, uint64_t seed,
                                                                 uint64_t sid0, const float* __restrict__ scale,
                                                                 float* __restrict__ wave, int n_iter, float mom) {
-    __shared__ float2 tile[3][kFftTile];
+    __shared__ v2f tile[3][kFftTile];
     __shared__ float ybuf[2][2][kNR];     // [ping-pong][0: centre column, 1: halves of columns 0 and 2][n]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const size_t b = blockIdx.x;
-    float2* mytile = tile[w];
+    v2f* mytile = tile[w];
 
     FftTwiddles tw;
     load_twiddles(tw, d.tw512, lane);
@@ -63,27 +63,27 @@ __global__ __launch_bounds__(kGlThreads) void griffinlim_kernel(DspDev d, const 
     //   column 0: n < 512 -> s[512-n] (reflection), else s[n-512]
     //   column 1: s[n]
     //   column 2: n < 512 -> s[n+512], else s[1534-n] (reflection)
-    float2 wk[4], wsyn[8], cw[8];
+    v2f wkh[4], wsyn[8], cw[8];
     int src0[8], src1[8];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) wk[t] = d.tw1024[lane + 64 * t];
+    for (int t = 0; t < 4; ++t) wkh[t] = cscale(reinterpret_cast<const v2f*>(d.tw1024)[lane + 64 * t], 0.5f);
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
         const int m = lane + 64 * t;
-        const float2 ww = reinterpret_cast<const float2*>(d.window)[m];
-        wsyn[t] = make_float2(ww.x * (1.0f / 512.0f), ww.y * (1.0f / 512.0f));
+        const v2f ww = reinterpret_cast<const v2f*>(d.window)[m];
+        wsyn[t] = cscale(ww, 1.0f / 512.0f);
         const int n0 = 2 * m, n1 = n0 + 1;
         int i0, i1;
         if (w == 1) { i0 = n0; i1 = n1; }
         else if (w == 0) { i0 = n0 < 512 ? 512 - n0 : n0 - 512; i1 = n1 < 512 ? 512 - n1 : n1 - 512; }
         else { i0 = n0 < 512 ? n0 + 512 : 1534 - n0; i1 = n1 < 512 ? n1 + 512 : 1534 - n1; }
         src0[t] = i0; src1[t] = i1;
-        cw[t] = make_float2(ww.x * d.inv_env[i0], ww.y * d.inv_env[i1]);
+        cw[t] = mk2(ww[0] * d.inv_env[i0], ww[1] * d.inv_env[i1]);
     }
 
     // per-lane state: the 4 bin pairs (k, 512-k), k = lane + 64 t, plus bin 256 (meaningful in lane 0)
     float mlo[4], mhi[4], mmid;
-    float2 alo[4], ahi[4], amid, plo[4], phi[4], pmid;
+    v2f alo[4], ahi[4], amid, plo[4], phi[4], pmid;
     {
         const size_t row = (b * 3 + w) * kBins;
 #pragma unroll
@@ -93,42 +93,42 @@ __global__ __launch_bounds__(kGlThreads) void griffinlim_kernel(DspDev d, const 
             mhi[t] = mag != nullptr ? mag[row + kh] : 1.0f;
             alo[t] = init != nullptr ? init[row + k] : rand_angle(seed, sid0 + b, w, k);
             ahi[t] = init != nullptr ? init[row + kh] : rand_angle(seed, sid0 + b, w, kh);
-            plo[t] = make_float2(0.0f, 0.0f);
-            phi[t] = make_float2(0.0f, 0.0f);
+            plo[t] = mk2(0.0f, 0.0f);
+            phi[t] = mk2(0.0f, 0.0f);
         }
         mmid = mag != nullptr ? mag[row + 256] : 1.0f;
         amid = init != nullptr ? init[row + 256] : rand_angle(seed, sid0 + b, w, 256);
-        pmid = make_float2(0.0f, 0.0f);
+        pmid = mk2(0.0f, 0.0f);
     }
 
     // a = rebuilt - m * tprev; tprev = rebuilt; angles = a / (|a| + 1e-16)   (v_sqrt / v_rcp: 1 ulp)
-    auto update = [mom](float2 reb, float2& prev, float2& ang) {
-        const float ax = reb.x - mom * prev.x, ay = reb.y - mom * prev.y;
+    auto update = [mom](v2f reb, v2f& prev, v2f& ang) {
+        const v2f a = reb - prev * mom;
         prev = reb;
-        const float inv = __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(fmaf(ax, ax, ay * ay)) + 1e-16f);
-        ang = make_float2(ax * inv, ay * inv);
+        const float inv = __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(fmaf(a[0], a[0], a[1] * a[1])) + 1e-16f);
+        ang = a * inv;
     };
 
-    float2 v[8], xlo[4], xhi[4], xmid;
+    v2f v[8], xlo[4], xhi[4], xmid;
     for (int it = 0;; ++it) {
         // ---- istft of angles * magnitude: Hermitian merge, inverse FFT, synthesis window, overlap-add lines
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            xlo[t] = make_float2(alo[t].x * mlo[t], alo[t].y * mlo[t]);
-            xhi[t] = make_float2(ahi[t].x * mhi[t], ahi[t].y * mhi[t]);
+            xlo[t] = alo[t] * mlo[t];
+            xhi[t] = ahi[t] * mhi[t];
         }
-        xmid = make_float2(amid.x * mmid, amid.y * mmid);
-        irfft_merge_pairs(xlo, xhi, xmid, wk, lane, v);
+        xmid = amid * mmid;
+        irfft_merge_pairs(xlo, xhi, xmid, wkh, lane, v);
         fft512<true>(v, tw, mytile, lane);
         float* y1 = ybuf[it & 1][0];
         float* yo = ybuf[it & 1][1];
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             const int n0 = 2 * (lane + 64 * t);
-            const float2 y = make_float2(v[t].x * wsyn[t].x, v[t].y * wsyn[t].y);
-            if (w == 1) *reinterpret_cast<float2*>(y1 + n0) = y;
-            else if (w == 0) { if (t >= 4) *reinterpret_cast<float2*>(yo + n0 - 512) = y; }
-            else { if (t < 4) *reinterpret_cast<float2*>(yo + n0 + 512) = y; }
+            const v2f y = v[t] * wsyn[t];
+            if (w == 1) *reinterpret_cast<v2f*>(y1 + n0) = y;
+            else if (w == 0) { if (t >= 4) *reinterpret_cast<v2f*>(yo + n0 - 512) = y; }
+            else { if (t < 4) *reinterpret_cast<v2f*>(yo + n0 + 512) = y; }
         }
         __syncthreads();
         if (it == n_iter) {
@@ -141,9 +141,9 @@ __global__ __launch_bounds__(kGlThreads) void griffinlim_kernel(DspDev d, const 
         // ---- stft of the rebuilt signal (centre, reflect): this wave's column, analysis window
 #pragma unroll
         for (int t = 0; t < 8; ++t)
-            v[t] = make_float2((y1[src0[t]] + yo[src0[t]]) * cw[t].x, (y1[src1[t]] + yo[src1[t]]) * cw[t].y);
+            v[t] = mk2(y1[src0[t]] + yo[src0[t]], y1[src1[t]] + yo[src1[t]]) * cw[t];
         fft512<false>(v, tw, mytile, lane);
-        rfft_split_pairs(v, wk, lane, xlo, xhi, xmid);
+        rfft_split_pairs(v, wkh, lane, xlo, xhi, xmid);
         // ---- phase update with momentum
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -158,7 +158,7 @@ void launch_griffinlim(const DspDev& d, const float* mag, const float* init, uin
                        const float* scale, float* wave, int B, int n_iter, float momentum, hipStream_t st) {
     const float mom = momentum / (1.0f + momentum);
     hipLaunchKernelGGL(griffinlim_kernel, dim3(B), dim3(kGlThreads), 0, st, d, mag,
-                       reinterpret_cast<const float2*>(init), seed, sid0, scale, wave, n_iter, mom);
+                       reinterpret_cast<const v2f*>(init), seed, sid0, scale, wave, n_iter, mom);
 }
 
 }  // namespace dn

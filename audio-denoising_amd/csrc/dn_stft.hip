@@ -23,7 +23,7 @@ __global__ __launch_bounds__(kStftThreads) void stft_kernel(DspDev d, const floa
                                                             float2* __restrict__ spec, float* __restrict__ mel,
                                                             float* __restrict__ peak_out, uint32_t flags) {
     __shared__ float xs[kNR];
-    __shared__ float2 tile[3][kFftTile];
+    __shared__ v2f tile[3][kFftTile];
     __shared__ float magbuf[3][kBins + 7];
     __shared__ float red[3];
 
@@ -65,31 +65,41 @@ __global__ __launch_bounds__(kStftThreads) void stft_kernel(DspDev d, const floa
     // ---- P4: column w of the centred STFT: padded position p = 512 w + n, source i = p - 512 reflected
     FftTwiddles tw;
     load_twiddles(tw, d.tw512, lane);
-    float2 wk[8], v[8];
+    v2f wkh[4], v[8];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) wkh[t] = cscale(reinterpret_cast<const v2f*>(d.tw1024)[lane + 64 * t], 0.5f);
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
         const int m = lane + 64 * t;
-        wk[t] = d.tw1024[m];
         const int n0 = 2 * m;
         int i0 = w * 512 + n0 - 512, i1 = i0 + 1;
         i0 = i0 < 0 ? -i0 : (i0 >= kNR ? 2 * kNR - 2 - i0 : i0);
         i1 = i1 < 0 ? -i1 : (i1 >= kNR ? 2 * kNR - 2 - i1 : i1);
-        const float2 ww = reinterpret_cast<const float2*>(d.window)[m];
-        v[t] = make_float2(xs[i0] * ww.x, xs[i1] * ww.y);
+        const v2f ww = reinterpret_cast<const v2f*>(d.window)[m];
+        v[t] = mk2(xs[i0] * ww[0], xs[i1] * ww[1]);
     }
-    const float xn = rfft1024(v, tw, wk, tile[w], tile[w], lane);
+    fft512<false>(v, tw, tile[w], lane);
+    // Hermitian split in pair order: this lane gets bins k = lane + 64 t and 512 - k (t < 4); lane 0 also bin 256
+    v2f lo[4], hi[4], mid;
+    rfft_split_pairs(v, wkh, lane, lo, hi, mid);
 
     if (WRITE_SPEC) {
-        float2* srow = spec + (b * 3 + w) * kBins;
+        v2f* srow = reinterpret_cast<v2f*>(spec) + (b * 3 + w) * kBins;
 #pragma unroll
-        for (int t = 0; t < 8; ++t) srow[lane + 64 * t] = v[t];
-        if (lane == 0) srow[512] = make_float2(xn, 0.0f);
+        for (int t = 0; t < 4; ++t) {
+            srow[lane + 64 * t] = lo[t];
+            srow[512 - (lane + 64 * t)] = hi[t];
+        }
+        if (lane == 0) srow[256] = mid;
     }
     if (WRITE_MEL) {
         // ---- P5: magnitude -> banded mel filterbank -> log1p; P6: rows are already (B,3,M)
 #pragma unroll
-        for (int t = 0; t < 8; ++t) magbuf[w][lane + 64 * t] = hypotf(v[t].x, v[t].y);
-        if (lane == 0) magbuf[w][512] = fabsf(xn);
+        for (int t = 0; t < 4; ++t) {
+            magbuf[w][lane + 64 * t] = hypotf(lo[t][0], lo[t][1]);
+            magbuf[w][512 - (lane + 64 * t)] = hypotf(hi[t][0], hi[t][1]);
+        }
+        if (lane == 0) magbuf[w][256] = hypotf(mid[0], mid[1]);
         wave_sync();
         float* mrow = mel + (b * 3 + w) * d.n_mels;
         for (int m = lane; m < d.n_mels; m += 64) {

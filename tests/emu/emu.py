@@ -17,7 +17,7 @@ sys.path.insert(0, REPO)
 
 def build(force=False):
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
-    deps = srcs + glob.glob(os.path.join(CSRC, "*.hpp")) + [os.path.join(HERE, "hip", "hip_runtime.h"),
+    deps = srcs + glob.glob(os.path.join(CSRC, "*.hpp")) + [os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(HERE, "dn_cpx.hpp"),
                                                            os.path.join(REPO, "include", "dn_denoise.h")]
     if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= max(os.path.getmtime(d) for d in deps):
         return OUT
