@@ -8,8 +8,8 @@
 // find these forms from scalar source (it emitted ~25 % v_mov in the Griffin-Lim loop), hence the
 // inline asm; all of it is plain VALU (no manual wait states needed).
 //
-// (The host-emulation test tier supplies an arithmetic-only header of the same name first on its
-// include path; see tests/emu/dn_cpx.hpp.)
+// This header is included as <dn_cpx.hpp> (the build adds -I.), so a test build for another host can
+// put an arithmetic-only header of the same name ahead of it on the include path.
 #pragma once
 #include <hip/hip_runtime.h>
 
