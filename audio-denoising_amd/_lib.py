@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libdn_denoise.so")
 SYMBOLS = (
     "dn_model_create", "dn_model_destroy", "dn_cell_forward", "dn_dsp_create", "dn_dsp_destroy",
     "dn_dsp_get_tables", "dn_stft", "dn_stft_mel_log1p", "dn_mel_scale", "dn_invmel", "dn_residual_invmel",
-    "dn_griffinlim", "dn_istft", "dn_workspace_bytes", "dn_process_frame", "dn_stream_step",
+    "dn_griffinlim", "dn_synthesis", "dn_istft", "dn_workspace_bytes", "dn_process_frame", "dn_stream_step",
     "dn_last_error", "dn_abi_version",
 )
 
@@ -70,6 +70,7 @@ class DnLib:
         L.dn_invmel.argtypes = [vp, p, p, i32, i32, vp]
         L.dn_residual_invmel.argtypes = [vp, p, p, p, i32, i32, vp]
         L.dn_griffinlim.argtypes = [vp, p, p, u64, u64, p, p, i32, i32, f32, vp]
+        L.dn_synthesis.argtypes = [vp, p, p, p, u64, u64, p, p, i32, i32, f32, vp]
         L.dn_istft.argtypes = [vp, p, p, i32, vp]
         L.dn_workspace_bytes.argtypes = [vp, i32]
         L.dn_workspace_bytes.restype = C.c_size_t

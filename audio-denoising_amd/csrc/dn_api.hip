@@ -494,6 +494,17 @@ int dn_griffinlim(const dn_dsp* d, const float* mag, const float* init_angles, u
     return check_launch("griffinlim_kernel");
 }
 
+int dn_synthesis(const dn_dsp* d, const float* x, const float* diff, const float* init_angles, uint64_t seed, uint64_t stream_id0,
+                 const float* scale, float* wave, int32_t B, int32_t n_iter, float momentum, void* stream) {
+    if (!d || !x || !diff || !wave) return fail(DN_ERR_INVALID, "dn_synthesis: null argument");
+    if (d->cfg.n_mels <= 0) return fail(DN_ERR_INVALID, "plan was created without mel stages");
+    if (B < 0 || n_iter < 0) return fail(DN_ERR_INVALID, "dn_synthesis: negative size");
+    if (!(momentum >= 0.0f && momentum < 1.0f)) return fail(DN_ERR_INVALID, "momentum must be in [0, 1)");
+    if (B == 0) return DN_OK;
+    dn::launch_synthesis(d->view, x, diff, init_angles, seed, stream_id0, scale, wave, B, n_iter, momentum, as_stream(stream));
+    return check_launch("griffinlim_kernel<from mel>");
+}
+
 int dn_istft(const dn_dsp* d, const float* spec, float* wave, int32_t B, void* stream) {
     if (!d || !spec || !wave) return fail(DN_ERR_INVALID, "dn_istft: null argument");
     if (B < 0) return fail(DN_ERR_INVALID, "dn_istft: negative batch");
@@ -526,8 +537,7 @@ int dn_process_frame(const dn_model* m, const dn_dsp* d, const float* frames, fl
     float* ws = static_cast<float*>(workspace);
     float* mel_in = ws;
     float* diff = mel_residual_out ? mel_residual_out : mel_in + (size_t)B * 3 * M;
-    float* lin = mel_in + (size_t)B * 6 * M;
-    float* peak = lin + (size_t)B * 3 * K;
+    float* peak = mel_in + (size_t)B * 6 * M + (size_t)B * 3 * K;
     BiasSet* bs = nullptr;
     int rc = build_bias(const_cast<dn_model*>(m), C, &bs);
     if (rc != DN_OK) return rc;
@@ -536,10 +546,9 @@ int dn_process_frame(const dn_model* m, const dn_dsp* d, const float* frames, fl
     if ((rc = check_launch("stft_kernel")) != DN_OK) return rc;
     dn::launch_cell(bs->view, mel_in, hx, diff, hx, B, 3, C, st);                                          // P7
     if ((rc = check_launch("cell_kernel")) != DN_OK) return rc;
-    dn::launch_invmel(d->view, mel_in, diff, lin, B * 3, st);                                              // P8-P10
-    if ((rc = check_launch("invmel_kernel")) != DN_OK) return rc;
-    dn::launch_griffinlim(d->view, lin, init_angles, seed, stream_id0, peak, out, B, n_iter, momentum, st); // P11 + `* peak`
-    return check_launch("griffinlim_kernel");
+    // P8-P12 in one launch: the inverse-mel contraction is the Griffin-Lim kernel's prologue (magnitudes stay in LDS)
+    dn::launch_synthesis(d->view, mel_in, diff, init_angles, seed, stream_id0, peak, out, B, n_iter, momentum, st);
+    return check_launch("griffinlim_kernel<from mel>");
 }
 
 int dn_stream_step(const dn_model* m, const dn_dsp* d, const float* hop_in, float* ring, float* ola, float* hx, float* hop_out,

@@ -42,7 +42,14 @@ __device__ __forceinline__ v2f rand_angle(uint64_t seed, uint64_t sid, int col, 
     return mk2((float)(c[0] >> 8) * (1.0f / 16777216.0f), (float)(c[1] >> 8) * (1.0f / 16777216.0f));
 }
 
+// FROM_MEL = false: `mag` is the linear magnitude [B][3][513] (GriffinLim / istft entry points).
+// FROM_MEL = true : `mag` is the model input x [B][3][M] and `diff` the model output; the prologue
+//                   computes P8-P10 in place -- leaky_relu(x - diff, 0.2), expm1, clamp, the pinv(fb^T)
+//                   contraction and relu (app3.py:203-211) -- into LDS, so the linear magnitudes never
+//                   touch HBM and the separate inverse-mel launch disappears from the fused hop.
+template <bool FROM_MEL>
 __global__ __launch_bounds__(kGlThreads) void griffinlim_kernel(DspDev d, const float* __restrict__ mag,
+                                                                const float* __restrict__ diff,
                                                                 const v2f* __restrict__ init, uint64_t seed,
                                                                 uint64_t sid0, const float* __restrict__ scale,
                                                                 float* __restrict__ wave, int n_iter, float mom) {
@@ -54,6 +61,44 @@ __global__ __launch_bounds__(kGlThreads) void griffinlim_kernel(DspDev d, const 
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const size_t b = blockIdx.x;
     v2f* mytile = tile[w];
+
+    // prologue scratch aliases the overlap-add lines (used only before the first iteration)
+    float* mm = &ybuf[0][0][0];           // [3][128]  mel magnitudes
+    float* lmag = &ybuf[1][0][0];         // [3][520]  linear magnitudes
+    if (FROM_MEL) {
+        const int M = d.n_mels;
+        for (int i = tid; i < 3 * M; i += kGlThreads) {
+            const int c = i / M, m = i - c * M;
+            float v = mag[(b * 3 + c) * M + m] - diff[(b * 3 + c) * M + m];
+            v = v >= 0.0f ? v : 0.2f * v;              // leaky_relu, app3.py:204
+            mm[c * 128 + m] = fmaxf(expm1f(v), 0.0f);  // app3.py:207-208
+        }
+        __syncthreads();
+        // thread <-> bins tid, tid+192, tid+384: each pinv element is loaded once and used for all 3 columns
+        float acc[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) acc[r][0] = acc[r][1] = acc[r][2] = 0.0f;
+        const float* p = d.pinv_t + tid;
+        const bool third = tid + 384 < kBins;
+#pragma unroll 8
+        for (int m = 0; m < M; ++m) {
+            const float* pm = p + (size_t)m * d.pinv_stride;
+            const float p0 = pm[0], p1 = pm[192], p2 = third ? pm[384] : 0.0f;
+            const float m0 = mm[m], m1 = mm[128 + m], m2 = mm[256 + m];
+            acc[0][0] = fmaf(p0, m0, acc[0][0]); acc[0][1] = fmaf(p0, m1, acc[0][1]); acc[0][2] = fmaf(p0, m2, acc[0][2]);
+            acc[1][0] = fmaf(p1, m0, acc[1][0]); acc[1][1] = fmaf(p1, m1, acc[1][1]); acc[1][2] = fmaf(p1, m2, acc[1][2]);
+            acc[2][0] = fmaf(p2, m0, acc[2][0]); acc[2][1] = fmaf(p2, m1, acc[2][1]); acc[2][2] = fmaf(p2, m2, acc[2][2]);
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int k = tid + 192 * r;
+            if (k < kBins) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) lmag[c * 520 + k] = fmaxf(acc[r][c], 0.0f);    // relu + clamp, app3.py:210-211
+            }
+        }
+        __syncthreads();
+    }
 
     FftTwiddles tw;
     load_twiddles(tw, d.tw512, lane);
@@ -89,14 +134,14 @@ __global__ __launch_bounds__(kGlThreads) void griffinlim_kernel(DspDev d, const 
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int k = lane + 64 * t, kh = 512 - k;
-            mlo[t] = mag != nullptr ? mag[row + k] : 1.0f;
-            mhi[t] = mag != nullptr ? mag[row + kh] : 1.0f;
+            mlo[t] = FROM_MEL ? lmag[w * 520 + k] : (mag != nullptr ? mag[row + k] : 1.0f);
+            mhi[t] = FROM_MEL ? lmag[w * 520 + kh] : (mag != nullptr ? mag[row + kh] : 1.0f);
             alo[t] = init != nullptr ? init[row + k] : rand_angle(seed, sid0 + b, w, k);
             ahi[t] = init != nullptr ? init[row + kh] : rand_angle(seed, sid0 + b, w, kh);
             plo[t] = mk2(0.0f, 0.0f);
             phi[t] = mk2(0.0f, 0.0f);
         }
-        mmid = mag != nullptr ? mag[row + 256] : 1.0f;
+        mmid = FROM_MEL ? lmag[w * 520 + 256] : (mag != nullptr ? mag[row + 256] : 1.0f);
         amid = init != nullptr ? init[row + 256] : rand_angle(seed, sid0 + b, w, 256);
         pmid = mk2(0.0f, 0.0f);
     }
@@ -108,6 +153,8 @@ __global__ __launch_bounds__(kGlThreads) void griffinlim_kernel(DspDev d, const 
         const float inv = __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(fmaf(a[0], a[0], a[1] * a[1])) + 1e-16f);
         ang = a * inv;
     };
+
+    if (FROM_MEL) __syncthreads();        // the prologue scratch becomes the overlap-add lines
 
     v2f v[8], xlo[4], xhi[4], xmid;
     for (int it = 0;; ++it) {
@@ -157,7 +204,15 @@ __global__ __launch_bounds__(kGlThreads) void griffinlim_kernel(DspDev d, const 
 void launch_griffinlim(const DspDev& d, const float* mag, const float* init, uint64_t seed, uint64_t sid0,
                        const float* scale, float* wave, int B, int n_iter, float momentum, hipStream_t st) {
     const float mom = momentum / (1.0f + momentum);
-    hipLaunchKernelGGL(griffinlim_kernel, dim3(B), dim3(kGlThreads), 0, st, d, mag,
+    hipLaunchKernelGGL((griffinlim_kernel<false>), dim3(B), dim3(kGlThreads), 0, st, d, mag, (const float*)nullptr,
+                       reinterpret_cast<const v2f*>(init), seed, sid0, scale, wave, n_iter, mom);
+}
+
+// P8..P12 in one launch: residual -> mel magnitude -> inverse mel -> Griffin-Lim -> * peak.
+void launch_synthesis(const DspDev& d, const float* x, const float* diff, const float* init, uint64_t seed, uint64_t sid0,
+                      const float* scale, float* wave, int B, int n_iter, float momentum, hipStream_t st) {
+    const float mom = momentum / (1.0f + momentum);
+    hipLaunchKernelGGL((griffinlim_kernel<true>), dim3(B), dim3(kGlThreads), 0, st, d, x, diff,
                        reinterpret_cast<const v2f*>(init), seed, sid0, scale, wave, n_iter, mom);
 }
 

@@ -35,10 +35,10 @@ GL_ITERS = 32
 # algorithmic work per frame (real FFT of length N counted as 2.5 N log2 N = 25,600 flop)
 FLOP_PER_RFFT = 2.5 * N_FFT * 10
 GL_FFTS = GL_ITERS * 6 + 3
-GL_FLOP_PER_FRAME = GL_FFTS * FLOP_PER_RFFT                       # 4.992 MFLOP
+GL_FLOP_PER_FRAME = GL_FFTS * FLOP_PER_RFFT + 246240              # 4.992 MFLOP of FFTs + the fused inverse-mel contraction
 TOTAL_FLOP_PER_FRAME = 198 * FLOP_PER_RFFT + 2 * 246240 + 939150  # 6.50 MFLOP
 HBM_BYTES_PER_FRAME = 4 * N_FFT + 4 * N_FFT + 2 * 4 * 17 * 5       # 8,872 B compulsory
-GL_HBM_BYTES_PER_FRAME = 4 * 3 * N_STFT + 4 * N_FFT + 4            # kernel-level: magnitudes in, waveform out, peak
+GL_HBM_BYTES_PER_FRAME = 2 * 4 * 3 * N_MELS + 4 * N_FFT + 4        # kernel-level: model input + residual in, waveform out, peak
 PEAK_FP32_TFLOPS = 157.3                                          # MI355X_MICROARCH.md: vector == matrix fp32 peak
 PEAK_HBM_GBS = 8000.0
 
@@ -60,7 +60,7 @@ def build_denoiser(dev):
 
 
 def staged_kernel_times(dn, frames, hx, steps):
-    """The same four launches dn_process_frame makes, issued one ABI call each with HIP events in between
+    """The same three launches dn_process_frame makes, issued one ABI call each with HIP events in between
     (torch.cuda.Event on the stream the kernels are launched on).  Returns mean ms per kernel."""
     import ctypes as C
     from audio_denoising_amd import _lib
@@ -68,14 +68,13 @@ def staged_kernel_times(dn, frames, hx, steps):
     B = frames.shape[0]
     mel = torch.empty(B, 3, N_MELS, device=dev)
     diff = torch.empty_like(mel)
-    lin = torch.empty(B, 3, N_STFT, device=dev)
     peak = torch.empty(B, device=dev)
     out = torch.empty_like(frames)
     model_h = dn.model._native(dev)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    names = ["stft_mel_log1p", "cell", "residual_invmel", "griffinlim"]
+    names = ["stft_mel_log1p", "cell", "synthesis"]
     acc = dict.fromkeys(names, 0.0)
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(steps)]
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(steps)]
     for s in range(steps):
         e = ev[s]
         e[0].record()
@@ -84,10 +83,8 @@ def staged_kernel_times(dn, frames, hx, steps):
         e[1].record()
         lib.check(lib.dn_cell_forward(model_h, mel.data_ptr(), hx.data_ptr(), diff.data_ptr(), hx.data_ptr(), B, 3, N_MELS, N_MELS // 16, st))
         e[2].record()
-        lib.check(lib.dn_residual_invmel(plan.handle, mel.data_ptr(), diff.data_ptr(), lin.data_ptr(), B, 3, st))
+        lib.check(lib.dn_synthesis(plan.handle, mel.data_ptr(), diff.data_ptr(), None, 7 + s, 0, peak.data_ptr(), out.data_ptr(), B, GL_ITERS, 0.99, st))
         e[3].record()
-        lib.check(lib.dn_griffinlim(plan.handle, lin.data_ptr(), None, 7 + s, 0, peak.data_ptr(), out.data_ptr(), B, GL_ITERS, 0.99, st))
-        e[4].record()
     torch.cuda.synchronize()
     for s in range(steps):
         for i, n in enumerate(names):
@@ -192,7 +189,7 @@ def main():
         ms = 1e3 * elapsed / args.steps
         value = B * world * args.steps / elapsed
         kt = staged_kernel_times(dn, frames, hx, min(args.steps, 100))
-        gl_s = kt["griffinlim"] * 1e-3
+        gl_s = kt["synthesis"] * 1e-3
         ach = GL_FLOP_PER_FRAME * B / gl_s / 1e12
         traffic = None
         pmc = os.path.join(REPO, "profiles", "pmc_traffic.json")
@@ -207,11 +204,11 @@ def main():
                                    "(dari_tult weights, num_compressed_bins=5), 32-iter Griffin-Lim, device-RNG initial phases, hx carried",
                        "streams_per_gpu": B, "frames_per_step": B * world, "sample_rate": SR, "n_fft": N_FFT, "hop": HOP,
                        "n_mels": N_MELS, "griffinlim_iters": GL_ITERS, "parallelism": f"stream-sharded x{world} (no data-path collective)"},
-            "roofline": {"bound": "mfma", "kernel": "griffinlim_kernel", "achieved": round(ach, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+            "roofline": {"bound": "mfma", "kernel": "griffinlim_kernel<from mel> (P8-P12: inverse mel + 32-iter Griffin-Lim)", "achieved": round(ach, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
                          "note": "fp32 compute roof (FFT butterflies on the fp32 VALU; vector and matrix fp32 peaks are both 157.3 TF); "
-                                 "algorithmic = 195 rFFT-1024 x 25,600 flop per frame x 256 frames per launch",
-                         "launch_ms": round(kt["griffinlim"], 4),
+                                 "algorithmic = (195 rFFT-1024 x 25,600 + 246,240 inverse-mel) flop per frame x 256 frames per launch",
+                         "launch_ms": round(kt["synthesis"], 4),
                          "hbm_frac": round(GL_HBM_BYTES_PER_FRAME * B / gl_s / 1e9 / PEAK_HBM_GBS, 6)},
             "kernel_ms": {k: round(v, 4) for k, v in kt.items()},
             "whole_path": {"tflops": round(TOTAL_FLOP_PER_FRAME * value / 1e12, 3),

@@ -20,6 +20,7 @@
  *   dn_mel_scale                        app3.py:193      MelScale(mag)
  *   dn_invmel / dn_residual_invmel      app3.py:203-211  leaky_relu(in-out), expm1, clamp, InverseMelScale, clamp
  *   dn_griffinlim                       app3.py:213-217  GriffinLim(power=1)(lin) (* peak)
+ *   dn_synthesis                        app3.py:203-217  residual .. InverseMelScale .. GriffinLim (* peak), one launch
  *   dn_istft                            server.py:174,216 InverseSpectrogram
  *   dn_process_frame                    app3.py:178-217  the whole per-hop loop body for B streams
  *   dn_stream_step                      app3.py:178-226  the same plus ring buffer / overlap-add state (P12)
@@ -135,6 +136,13 @@ int dn_griffinlim(const dn_dsp* d, const float* mag, const float* init_angles, u
                   uint64_t stream_id0, const float* scale, float* wave, int32_t B, int32_t n_iter,
                   float momentum, void* stream);
 
+/* P8..P12 in ONE launch (app3.py:203-217): x, diff [dev][B][3][M] (model input and model output) ->
+ * leaky_relu(x - diff, 0.2), expm1, clamp, inverse mel, relu, Griffin-Lim, * scale.  The linear magnitudes
+ * stay in LDS.  init_angles / seed / stream_id0 / scale as for dn_griffinlim. */
+int dn_synthesis(const dn_dsp* d, const float* x, const float* diff, const float* init_angles, uint64_t seed,
+                 uint64_t stream_id0, const float* scale, float* wave, int32_t B, int32_t n_iter, float momentum,
+                 void* stream);
+
 /* torch.istft(center=True, length=None) of 3 columns: spec [dev][B][3][K] complex -> wave [dev][B][n_fft]. */
 int dn_istft(const dn_dsp* d, const float* spec, float* wave, int32_t B, void* stream);
 
@@ -144,7 +152,7 @@ size_t dn_workspace_bytes(const dn_dsp* d, int32_t B);
 /* The whole per-hop body for B streams (app3.py:178-217): frames [dev][B][n_fft] raw samples,
  * hx [dev][B][17][C] in/out, out [dev][B][n_fft] = GriffinLim(...) * peak.
  * mel_residual_out [dev][B][3][M] or NULL receives the model output (predicted_diff_mel).
- * workspace [dev] of dn_workspace_bytes(d, B) bytes. */
+ * workspace [dev] of dn_workspace_bytes(d, B) bytes.  Three launches: dn_stft_mel_log1p, dn_cell_forward, dn_synthesis. */
 int dn_process_frame(const dn_model* m, const dn_dsp* d, const float* frames, float* hx, float* out,
                      float* mel_residual_out, const float* init_angles, uint64_t seed, uint64_t stream_id0,
                      int32_t n_iter, float momentum, void* workspace, int32_t B, void* stream);
