@@ -124,6 +124,17 @@ struct dn_dsp {
     std::vector<float> fb, pinv, window;   // host copies [K][M], [K][M], [N]
 };
 
+struct dn_pipe {
+    const dn_model* m = nullptr;
+    const dn_dsp* d = nullptr;
+    int B = 0, C = 0;
+    hipStream_t front = nullptr, back = nullptr;
+    hipEvent_t ev_in = nullptr, ev_front[2] = {nullptr, nullptr}, ev_back[2] = {nullptr, nullptr};
+    float* scratch[2] = {nullptr, nullptr};   // per slot: mel [B][3][M], residual [B][3][M], peak [B]
+    uint64_t seq = 0;
+    BiasSet* bs = nullptr;
+};
+
 namespace {
 
 int build_bias(dn_model* m, int C, BiasSet** out) {
@@ -568,6 +579,78 @@ int dn_stream_step(const dn_model* m, const dn_dsp* d, const float* hop_in, floa
     if (rc != DN_OK) return rc;
     dn::launch_stream_ola(y, ola, hop_out, B, st);
     return check_launch("stream_ola_kernel");
+}
+
+int dn_pipe_create(const dn_model* m, const dn_dsp* d, int32_t B, dn_pipe** out) {
+    if (!m || !d || !out) return fail(DN_ERR_INVALID, "dn_pipe_create: null argument");
+    if (B <= 0) return fail(DN_ERR_INVALID, "dn_pipe_create: batch must be positive");
+    if (d->cfg.n_mels <= 0 || d->cfg.n_mels % 16) return fail(DN_ERR_INVALID, "n_mels must be a positive multiple of 16");
+    const int C = d->cfg.n_mels / 16;
+    if (C > dn::kMaxC) return fail(DN_ERR_UNSUPPORTED, "n_mels/16 exceeds the cell kernel's limit");
+    dn_pipe* p = new dn_pipe();
+    p->m = m; p->d = d; p->B = B; p->C = C;
+    int rc = build_bias(const_cast<dn_model*>(m), C, &p->bs);
+    if (rc != DN_OK) { delete p; return rc; }
+    const size_t slot = ((size_t)B * (6 * d->cfg.n_mels + 1) * sizeof(float) + 255) & ~size_t(255);
+    hipError_t e = hipStreamCreateWithFlags(&p->front, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->back, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_in, hipEventDisableTiming);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+        e = hipEventCreateWithFlags(&p->ev_front[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_back[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->scratch[i]), slot);
+    }
+    if (e != hipSuccess) { dn_pipe_destroy(p); return fail(DN_ERR_HIP, std::string("dn_pipe_create: ") + hipGetErrorString(e)); }
+    *out = p;
+    return DN_OK;
+}
+
+void dn_pipe_destroy(dn_pipe* p) {
+    if (!p) return;
+    if (p->front) (void)hipStreamSynchronize(p->front);
+    if (p->back) (void)hipStreamSynchronize(p->back);
+    for (int i = 0; i < 2; ++i) {
+        if (p->scratch[i]) (void)hipFree(p->scratch[i]);
+        if (p->ev_front[i]) (void)hipEventDestroy(p->ev_front[i]);
+        if (p->ev_back[i]) (void)hipEventDestroy(p->ev_back[i]);
+    }
+    if (p->ev_in) (void)hipEventDestroy(p->ev_in);
+    if (p->front) (void)hipStreamDestroy(p->front);
+    if (p->back) (void)hipStreamDestroy(p->back);
+    delete p;
+}
+
+int dn_pipe_submit(dn_pipe* p, const float* frames, float* hx, float* out, const float* init_angles, uint64_t seed,
+                   uint64_t stream_id0, int32_t n_iter, float momentum, void* stream) {
+    if (!p || !frames || !hx || !out) return fail(DN_ERR_INVALID, "dn_pipe_submit: null argument");
+    if (n_iter < 0) return fail(DN_ERR_INVALID, "dn_pipe_submit: negative n_iter");
+    if (!(momentum >= 0.0f && momentum < 1.0f)) return fail(DN_ERR_INVALID, "momentum must be in [0, 1)");
+    const int s = (int)(p->seq & 1), B = p->B, M = p->d->cfg.n_mels;
+    float* mel = p->scratch[s];
+    float* diff = mel + (size_t)B * 3 * M;
+    float* peak = diff + (size_t)B * 3 * M;
+    int rc;
+    DN_HIP(hipEventRecord(p->ev_in, as_stream(stream)));
+    DN_HIP(hipStreamWaitEvent(p->front, p->ev_in, 0));
+    if (p->seq >= 2) DN_HIP(hipStreamWaitEvent(p->front, p->ev_back[s], 0));      // scratch slot s is free again
+    dn::launch_stft(p->d->view, frames, nullptr, mel, peak, B, DN_PEAK_NORMALIZE | DN_PRE_WINDOW, p->front);   // P1-P6
+    if ((rc = check_launch("stft_kernel")) != DN_OK) return rc;
+    dn::launch_cell(p->bs->view, mel, hx, diff, hx, B, 3, p->C, p->front);                                      // P7
+    if ((rc = check_launch("cell_kernel")) != DN_OK) return rc;
+    DN_HIP(hipEventRecord(p->ev_front[s], p->front));
+    DN_HIP(hipStreamWaitEvent(p->back, p->ev_front[s], 0));
+    dn::launch_synthesis(p->d->view, mel, diff, init_angles, seed, stream_id0, peak, out, B, n_iter, momentum, p->back);   // P8-P12
+    if ((rc = check_launch("griffinlim_kernel<from mel>")) != DN_OK) return rc;
+    DN_HIP(hipEventRecord(p->ev_back[s], p->back));
+    p->seq++;
+    return DN_OK;
+}
+
+int dn_pipe_flush(dn_pipe* p, void* stream) {
+    if (!p) return fail(DN_ERR_INVALID, "dn_pipe_flush: null pipe");
+    if (p->seq == 0) return DN_OK;
+    DN_HIP(hipStreamWaitEvent(as_stream(stream), p->ev_back[(p->seq - 1) & 1], 0));   // back stream is in order
+    return DN_OK;
 }
 
 }  // extern "C"

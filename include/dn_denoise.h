@@ -24,6 +24,7 @@
  *   dn_istft                            server.py:174,216 InverseSpectrogram
  *   dn_process_frame                    app3.py:178-217  the whole per-hop loop body for B streams
  *   dn_stream_step                      app3.py:178-226  the same plus ring buffer / overlap-add state (P12)
+ *   dn_pipe_*                           app3.py:178-217  the same hop, consecutive hops overlapped on two HIP streams
  *
  * Memory layouts (row-major, fp32; "complex" = interleaved re,im float pairs):
  *   frames      [B][n_fft]
@@ -163,6 +164,21 @@ int dn_process_frame(const dn_model* m, const dn_dsp* d, const float* frames, fl
 int dn_stream_step(const dn_model* m, const dn_dsp* d, const float* hop_in, float* ring, float* ola, float* hx,
                    float* hop_out, const float* init_angles, uint64_t seed, uint64_t stream_id0, int32_t n_iter,
                    float momentum, void* workspace, int32_t B, void* stream);
+
+/* ---- Two-stream hop pipeline -------------------------------------------------------------------------
+ * Consecutive hops depend on each other only through hx (the model); hop n's synthesis (P8-P12, ~3/4 of
+ * the time) is independent of hop n+1's analysis + model (P1-P7).  A dn_pipe owns two internal HIP streams,
+ * events and double-buffered scratch and overlaps them: submit(n+1) runs its analysis + model on the front
+ * stream while the back stream is still in hop n's Griffin-Lim.  Per call the work is ordered AFTER
+ * everything already enqueued on `stream` (the caller's stream); results are ordered before whatever the
+ * caller enqueues after dn_pipe_flush(pipe, stream).  `frames`, `out` and `hx` must not be touched by the
+ * caller between a submit and the flush that covers it (hx is advanced in place, hop by hop). */
+typedef struct dn_pipe dn_pipe;
+int dn_pipe_create(const dn_model* m, const dn_dsp* d, int32_t B, dn_pipe** out);
+void dn_pipe_destroy(dn_pipe* p);
+int dn_pipe_submit(dn_pipe* p, const float* frames, float* hx, float* out, const float* init_angles, uint64_t seed,
+                   uint64_t stream_id0, int32_t n_iter, float momentum, void* stream);
+int dn_pipe_flush(dn_pipe* p, void* stream);
 
 const char* dn_last_error(void);
 int dn_abi_version(void);

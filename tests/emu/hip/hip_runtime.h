@@ -48,6 +48,16 @@ inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n); return *p ? 0 
 inline hipError_t hipFree(void* p) { free(p); return 0; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return 0; }
 inline hipError_t hipGetLastError() { return 0; }
+// streams and events: the emulation is synchronous, so these only have to exist
+typedef struct dn_emu_event* hipEvent_t;
+constexpr unsigned hipStreamNonBlocking = 1, hipEventDisableTiming = 2;
+inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return 0; }
+inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return 0; }
+inline hipError_t hipEventDestroy(hipEvent_t) { return 0; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
 inline const char* hipGetErrorString(hipError_t) { return "emulated"; }
 
 namespace dn_emu {
