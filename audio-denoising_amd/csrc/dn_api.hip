@@ -130,7 +130,7 @@ struct dn_pipe {
     int B = 0, C = 0;
     hipStream_t front = nullptr, back = nullptr;
     hipEvent_t ev_in = nullptr, ev_front[2] = {nullptr, nullptr}, ev_back[2] = {nullptr, nullptr};
-    float* scratch[2] = {nullptr, nullptr};   // per slot: mel [B][3][M], residual [B][3][M], peak [B]
+    float* scratch[2] = {nullptr, nullptr};   // per slot: mel [B][3][M], residual [B][3][M], peak [B], lin [B][3][K]
     uint64_t seq = 0;
     BiasSet* bs = nullptr;
 };
@@ -591,7 +591,7 @@ int dn_pipe_create(const dn_model* m, const dn_dsp* d, int32_t B, dn_pipe** out)
     p->m = m; p->d = d; p->B = B; p->C = C;
     int rc = build_bias(const_cast<dn_model*>(m), C, &p->bs);
     if (rc != DN_OK) { delete p; return rc; }
-    const size_t slot = ((size_t)B * (6 * d->cfg.n_mels + 1) * sizeof(float) + 255) & ~size_t(255);
+    const size_t slot = ((size_t)B * (6 * d->cfg.n_mels + 1 + 3 * (d->cfg.n_fft / 2 + 1)) * sizeof(float) + 255) & ~size_t(255);
     hipError_t e = hipStreamCreateWithFlags(&p->front, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->back, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_in, hipEventDisableTiming);
@@ -629,6 +629,7 @@ int dn_pipe_submit(dn_pipe* p, const float* frames, float* hx, float* out, const
     float* mel = p->scratch[s];
     float* diff = mel + (size_t)B * 3 * M;
     float* peak = diff + (size_t)B * 3 * M;
+    float* lin = peak + B;
     int rc;
     DN_HIP(hipEventRecord(p->ev_in, as_stream(stream)));
     DN_HIP(hipStreamWaitEvent(p->front, p->ev_in, 0));
@@ -637,10 +638,14 @@ int dn_pipe_submit(dn_pipe* p, const float* frames, float* hx, float* out, const
     if ((rc = check_launch("stft_kernel")) != DN_OK) return rc;
     dn::launch_cell(p->bs->view, mel, hx, diff, hx, B, 3, p->C, p->front);                                      // P7
     if ((rc = check_launch("cell_kernel")) != DN_OK) return rc;
+    // the front stream is off the critical path, so the inverse-mel contraction runs there as its own launch and the
+    // back stream carries Griffin-Lim only (the serial entry point dn_process_frame fuses it into the GL prologue)
+    dn::launch_invmel(p->d->view, mel, diff, lin, B * 3, p->front);                                              // P8-P10
+    if ((rc = check_launch("invmel_kernel")) != DN_OK) return rc;
     DN_HIP(hipEventRecord(p->ev_front[s], p->front));
     DN_HIP(hipStreamWaitEvent(p->back, p->ev_front[s], 0));
-    dn::launch_synthesis(p->d->view, mel, diff, init_angles, seed, stream_id0, peak, out, B, n_iter, momentum, p->back);   // P8-P12
-    if ((rc = check_launch("griffinlim_kernel<from mel>")) != DN_OK) return rc;
+    dn::launch_griffinlim(p->d->view, lin, init_angles, seed, stream_id0, peak, out, B, n_iter, momentum, p->back);   // P11-P12
+    if ((rc = check_launch("griffinlim_kernel")) != DN_OK) return rc;
     DN_HIP(hipEventRecord(p->ev_back[s], p->back));
     p->seq++;
     return DN_OK;

@@ -169,13 +169,14 @@ __global__ __launch_bounds__(kGlThreads) void griffinlim_kernel(DspDev d, const 
         fft512<true>(v, tw, mytile, lane);
         float* y1 = ybuf[it & 1][0];
         float* yo = ybuf[it & 1][1];
+        {
+            // column 1 -> y1[n]; column 0 keeps its second half -> yo[n-512]; column 2 its first half -> yo[n+512]
+            // (the other halves fall outside the samples the istft trim keeps and are simply not stored)
+            float* ydst = w == 1 ? y1 : (w == 0 ? yo - 512 : yo + 512);
+            const int t_lo = w == 0 ? 4 : 0, t_hi = w == 2 ? 4 : 8;
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const int n0 = 2 * (lane + 64 * t);
-            const v2f y = v[t] * wsyn[t];
-            if (w == 1) *reinterpret_cast<v2f*>(y1 + n0) = y;
-            else if (w == 0) { if (t >= 4) *reinterpret_cast<v2f*>(yo + n0 - 512) = y; }
-            else { if (t < 4) *reinterpret_cast<v2f*>(yo + n0 + 512) = y; }
+            for (int t = 0; t < 8; ++t)
+                if (t >= t_lo && t < t_hi) *reinterpret_cast<v2f*>(ydst + 2 * (lane + 64 * t)) = v[t] * wsyn[t];
         }
         __syncthreads();
         if (it == n_iter) {

@@ -40,18 +40,29 @@ __global__ __launch_bounds__(kInvThreads) void invmel_kernel(DspDev d, const flo
         mm[r][m] = v;
     }
     __syncthreads();
-    for (int k = tid; k < kBins; k += kInvThreads) {
-        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
-        const float* p = d.pinv_t + k;
-        for (int m = 0; m < M; ++m) {
-            const float pv = p[(size_t)m * d.pinv_stride];
-            a0 = fmaf(pv, mm[0][m], a0);
-            a1 = fmaf(pv, mm[1][m], a1);
-            a2 = fmaf(pv, mm[2][m], a2);
+    // thread <-> bins tid, tid+192, tid+384: three independent load streams, 8 rows of pinv_t in flight each
+    float acc[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) acc[r][0] = acc[r][1] = acc[r][2] = 0.0f;
+    const float* p = d.pinv_t + tid;
+    const bool third = tid + 2 * kInvThreads < kBins;
+#pragma unroll 8
+    for (int m = 0; m < M; ++m) {
+        const float* pm = p + (size_t)m * d.pinv_stride;
+        const float p0 = pm[0], p1 = pm[kInvThreads], p2 = third ? pm[2 * kInvThreads] : 0.0f;
+        const float m0 = mm[0][m], m1 = mm[1][m], m2 = mm[2][m];
+        acc[0][0] = fmaf(p0, m0, acc[0][0]); acc[0][1] = fmaf(p0, m1, acc[0][1]); acc[0][2] = fmaf(p0, m2, acc[0][2]);
+        acc[1][0] = fmaf(p1, m0, acc[1][0]); acc[1][1] = fmaf(p1, m1, acc[1][1]); acc[1][2] = fmaf(p1, m2, acc[1][2]);
+        acc[2][0] = fmaf(p2, m0, acc[2][0]); acc[2][1] = fmaf(p2, m1, acc[2][1]); acc[2][2] = fmaf(p2, m2, acc[2][2]);
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int k = tid + kInvThreads * r;
+        if (k < kBins) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                if (r0 + c < (size_t)rows) lin[(r0 + c) * kBins + k] = fmaxf(acc[r][c], 0.0f);
         }
-        if (r0 + 0 < (size_t)rows) lin[(r0 + 0) * kBins + k] = fmaxf(a0, 0.0f);
-        if (r0 + 1 < (size_t)rows) lin[(r0 + 1) * kBins + k] = fmaxf(a1, 0.0f);
-        if (r0 + 2 < (size_t)rows) lin[(r0 + 2) * kBins + k] = fmaxf(a2, 0.0f);
     }
 }
 
