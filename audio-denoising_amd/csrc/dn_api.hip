@@ -128,11 +128,11 @@ struct dn_pipe {
     const dn_model* m = nullptr;
     const dn_dsp* d = nullptr;
     int B = 0, C = 0;
-    hipStream_t front = nullptr, back = nullptr;
-    hipEvent_t ev_in = nullptr, ev_front[2] = {nullptr, nullptr}, ev_back[2] = {nullptr, nullptr};
     float* scratch[2] = {nullptr, nullptr};   // per slot: mel [B][3][M], residual [B][3][M], peak [B], lin [B][3][K]
     uint64_t seq = 0;
     BiasSet* bs = nullptr;
+    bool pending = false;                     // a hop whose Griffin-Lim has not been launched yet
+    dn::HopArgs last{};                       // its back-half arguments
 };
 
 namespace {
@@ -592,31 +592,18 @@ int dn_pipe_create(const dn_model* m, const dn_dsp* d, int32_t B, dn_pipe** out)
     int rc = build_bias(const_cast<dn_model*>(m), C, &p->bs);
     if (rc != DN_OK) { delete p; return rc; }
     const size_t slot = ((size_t)B * (6 * d->cfg.n_mels + 1 + 3 * (d->cfg.n_fft / 2 + 1)) * sizeof(float) + 255) & ~size_t(255);
-    hipError_t e = hipStreamCreateWithFlags(&p->front, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->back, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_in, hipEventDisableTiming);
-    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
-        e = hipEventCreateWithFlags(&p->ev_front[i], hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_back[i], hipEventDisableTiming);
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->scratch[i]), slot);
+    for (int i = 0; i < 2; ++i) {
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p->scratch[i]), slot);
+        if (e != hipSuccess) { dn_pipe_destroy(p); return fail(DN_ERR_HIP, std::string("dn_pipe_create: ") + hipGetErrorString(e)); }
     }
-    if (e != hipSuccess) { dn_pipe_destroy(p); return fail(DN_ERR_HIP, std::string("dn_pipe_create: ") + hipGetErrorString(e)); }
     *out = p;
     return DN_OK;
 }
 
 void dn_pipe_destroy(dn_pipe* p) {
     if (!p) return;
-    if (p->front) (void)hipStreamSynchronize(p->front);
-    if (p->back) (void)hipStreamSynchronize(p->back);
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 2; ++i)
         if (p->scratch[i]) (void)hipFree(p->scratch[i]);
-        if (p->ev_front[i]) (void)hipEventDestroy(p->ev_front[i]);
-        if (p->ev_back[i]) (void)hipEventDestroy(p->ev_back[i]);
-    }
-    if (p->ev_in) (void)hipEventDestroy(p->ev_in);
-    if (p->front) (void)hipStreamDestroy(p->front);
-    if (p->back) (void)hipStreamDestroy(p->back);
     delete p;
 }
 
@@ -626,36 +613,35 @@ int dn_pipe_submit(dn_pipe* p, const float* frames, float* hx, float* out, const
     if (n_iter < 0) return fail(DN_ERR_INVALID, "dn_pipe_submit: negative n_iter");
     if (!(momentum >= 0.0f && momentum < 1.0f)) return fail(DN_ERR_INVALID, "momentum must be in [0, 1)");
     const int s = (int)(p->seq & 1), B = p->B, M = p->d->cfg.n_mels;
-    float* mel = p->scratch[s];
-    float* diff = mel + (size_t)B * 3 * M;
-    float* peak = diff + (size_t)B * 3 * M;
-    float* lin = peak + B;
-    int rc;
-    DN_HIP(hipEventRecord(p->ev_in, as_stream(stream)));
-    DN_HIP(hipStreamWaitEvent(p->front, p->ev_in, 0));
-    if (p->seq >= 2) DN_HIP(hipStreamWaitEvent(p->front, p->ev_back[s], 0));      // scratch slot s is free again
-    dn::launch_stft(p->d->view, frames, nullptr, mel, peak, B, DN_PEAK_NORMALIZE | DN_PRE_WINDOW, p->front);   // P1-P6
-    if ((rc = check_launch("stft_kernel")) != DN_OK) return rc;
-    dn::launch_cell(p->bs->view, mel, hx, diff, hx, B, 3, p->C, p->front);                                      // P7
-    if ((rc = check_launch("cell_kernel")) != DN_OK) return rc;
-    // the front stream is off the critical path, so the inverse-mel contraction runs there as its own launch and the
-    // back stream carries Griffin-Lim only (the serial entry point dn_process_frame fuses it into the GL prologue)
-    dn::launch_invmel(p->d->view, mel, diff, lin, B * 3, p->front);                                              // P8-P10
-    if ((rc = check_launch("invmel_kernel")) != DN_OK) return rc;
-    DN_HIP(hipEventRecord(p->ev_front[s], p->front));
-    DN_HIP(hipStreamWaitEvent(p->back, p->ev_front[s], 0));
-    dn::launch_griffinlim(p->d->view, lin, init_angles, seed, stream_id0, peak, out, B, n_iter, momentum, p->back);   // P11-P12
-    if ((rc = check_launch("griffinlim_kernel")) != DN_OK) return rc;
-    DN_HIP(hipEventRecord(p->ev_back[s], p->back));
+    dn::HopArgs a = p->last;                       // back half: the hop submitted before this one (if any)
+    a.back_B = p->pending ? B : 0;
+    a.frames = frames; a.hx = hx;                  // front half: this hop, into scratch slot s
+    a.mel = p->scratch[s];
+    a.diff = a.mel + (size_t)B * 3 * M;
+    a.peak = a.diff + (size_t)B * 3 * M;
+    a.lin = a.peak + B;
+    a.front_B = B; a.C = p->C;
+    dn::launch_hop(p->d->view, p->bs->view, a, as_stream(stream));
+    int rc = check_launch("hop_kernel");
+    if (rc != DN_OK) return rc;
+    // remember this hop's Griffin-Lim for the next launch
+    p->last.gl_lin = a.lin; p->last.gl_peak = a.peak; p->last.gl_init = init_angles;
+    p->last.gl_seed = seed; p->last.gl_sid0 = stream_id0; p->last.gl_out = out;
+    p->last.n_iter = n_iter; p->last.mom = momentum / (1.0f + momentum);
+    p->pending = true;
     p->seq++;
     return DN_OK;
 }
 
 int dn_pipe_flush(dn_pipe* p, void* stream) {
     if (!p) return fail(DN_ERR_INVALID, "dn_pipe_flush: null pipe");
-    if (p->seq == 0) return DN_OK;
-    DN_HIP(hipStreamWaitEvent(as_stream(stream), p->ev_back[(p->seq - 1) & 1], 0));   // back stream is in order
-    return DN_OK;
+    if (!p->pending) return DN_OK;
+    dn::HopArgs a = p->last;
+    a.back_B = p->B; a.front_B = 0; a.C = p->C;
+    a.frames = nullptr; a.hx = nullptr; a.mel = nullptr; a.diff = nullptr; a.peak = nullptr; a.lin = nullptr;
+    dn::launch_hop(p->d->view, p->bs->view, a, as_stream(stream));
+    p->pending = false;
+    return check_launch("hop_kernel(flush)");
 }
 
 }  // extern "C"

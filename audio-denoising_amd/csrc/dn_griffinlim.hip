@@ -14,192 +14,18 @@
 //   HBM       : magnitudes in (3*513 floats), waveform out (1024 floats).  That is all.
 // One __syncthreads per iteration (overlap-add hand-off between the three columns); every
 // FFT-internal exchange is wave-private.
-#include "dn_internal.hpp"
-#include "dn_wavefft.hpp"
+#include "dn_gl_body.hpp"
 
 namespace dn {
 
-constexpr int kGlThreads = 192;
-
-// Philox4x32-10 counter-based generator (Salmon et al. 2011).
-__device__ __forceinline__ void philox4x32(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
-        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
-        c[0] = n0; c[1] = (uint32_t)p1; c[2] = n2; c[3] = (uint32_t)p0;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-}
-
-// real, imag ~ U[0,1) independently (torch.rand(dtype=complex64) semantics), keyed by
-// (seed, global stream id, column, bin) so sharding streams over GPUs does not change results.
-__device__ __forceinline__ v2f rand_angle(uint64_t seed, uint64_t sid, int col, int bin) {
-    uint32_t c[4] = {(uint32_t)bin, (uint32_t)col, (uint32_t)sid, (uint32_t)(sid >> 32)};
-    philox4x32(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-    return mk2((float)(c[0] >> 8) * (1.0f / 16777216.0f), (float)(c[1] >> 8) * (1.0f / 16777216.0f));
-}
-
-// FROM_MEL = false: `mag` is the linear magnitude [B][3][513] (GriffinLim / istft entry points).
-// FROM_MEL = true : `mag` is the model input x [B][3][M] and `diff` the model output; the prologue
-//                   computes P8-P10 in place -- leaky_relu(x - diff, 0.2), expm1, clamp, the pinv(fb^T)
-//                   contraction and relu (app3.py:203-211) -- into LDS, so the linear magnitudes never
-//                   touch HBM and the separate inverse-mel launch disappears from the fused hop.
 template <bool FROM_MEL>
 __global__ __launch_bounds__(kGlThreads) void griffinlim_kernel(DspDev d, const float* __restrict__ mag,
                                                                 const float* __restrict__ diff,
                                                                 const v2f* __restrict__ init, uint64_t seed,
                                                                 uint64_t sid0, const float* __restrict__ scale,
                                                                 float* __restrict__ wave, int n_iter, float mom) {
-    __shared__ v2f tile[3][kFftTile];
-    __shared__ float ybuf[2][2][kNR];     // [ping-pong][0: centre column, 1: halves of columns 0 and 2][n]
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const size_t b = blockIdx.x;
-    v2f* mytile = tile[w];
-
-    // prologue scratch aliases the overlap-add lines (used only before the first iteration)
-    float* mm = &ybuf[0][0][0];           // [3][128]  mel magnitudes
-    float* lmag = &ybuf[1][0][0];         // [3][520]  linear magnitudes
-    if (FROM_MEL) {
-        const int M = d.n_mels;
-        for (int i = tid; i < 3 * M; i += kGlThreads) {
-            const int c = i / M, m = i - c * M;
-            float v = mag[(b * 3 + c) * M + m] - diff[(b * 3 + c) * M + m];
-            v = v >= 0.0f ? v : 0.2f * v;              // leaky_relu, app3.py:204
-            mm[c * 128 + m] = fmaxf(expm1f(v), 0.0f);  // app3.py:207-208
-        }
-        __syncthreads();
-        // thread <-> bins tid, tid+192, tid+384: each pinv element is loaded once and used for all 3 columns
-        float acc[3][3];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) acc[r][0] = acc[r][1] = acc[r][2] = 0.0f;
-        const float* p = d.pinv_t + tid;
-        const bool third = tid + 384 < kBins;
-#pragma unroll 8
-        for (int m = 0; m < M; ++m) {
-            const float* pm = p + (size_t)m * d.pinv_stride;
-            const float p0 = pm[0], p1 = pm[192], p2 = third ? pm[384] : 0.0f;
-            const float m0 = mm[m], m1 = mm[128 + m], m2 = mm[256 + m];
-            acc[0][0] = fmaf(p0, m0, acc[0][0]); acc[0][1] = fmaf(p0, m1, acc[0][1]); acc[0][2] = fmaf(p0, m2, acc[0][2]);
-            acc[1][0] = fmaf(p1, m0, acc[1][0]); acc[1][1] = fmaf(p1, m1, acc[1][1]); acc[1][2] = fmaf(p1, m2, acc[1][2]);
-            acc[2][0] = fmaf(p2, m0, acc[2][0]); acc[2][1] = fmaf(p2, m1, acc[2][1]); acc[2][2] = fmaf(p2, m2, acc[2][2]);
-        }
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const int k = tid + 192 * r;
-            if (k < kBins) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) lmag[c * 520 + k] = fmaxf(acc[r][c], 0.0f);    // relu + clamp, app3.py:210-211
-            }
-        }
-        __syncthreads();
-    }
-
-    FftTwiddles tw;
-    load_twiddles(tw, d.tw512, lane);
-
-    // lane constants: bin twiddles of the owned pairs, synthesis window / 512, analysis window * 1/envelope
-    // and the source sample indices of this column in the rebuilt signal s[0..1024):
-    //   column 0: n < 512 -> s[512-n] (reflection), else s[n-512]
-    //   column 1: s[n]
-    //   column 2: n < 512 -> s[n+512], else s[1534-n] (reflection)
-    v2f wkh[4], wsyn[8], cw[8];
-    int src0[8], src1[8];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) wkh[t] = cscale(reinterpret_cast<const v2f*>(d.tw1024)[lane + 64 * t], 0.5f);
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        const int m = lane + 64 * t;
-        const v2f ww = reinterpret_cast<const v2f*>(d.window)[m];
-        wsyn[t] = cscale(ww, 1.0f / 512.0f);
-        const int n0 = 2 * m, n1 = n0 + 1;
-        int i0, i1;
-        if (w == 1) { i0 = n0; i1 = n1; }
-        else if (w == 0) { i0 = n0 < 512 ? 512 - n0 : n0 - 512; i1 = n1 < 512 ? 512 - n1 : n1 - 512; }
-        else { i0 = n0 < 512 ? n0 + 512 : 1534 - n0; i1 = n1 < 512 ? n1 + 512 : 1534 - n1; }
-        src0[t] = i0; src1[t] = i1;
-        cw[t] = mk2(ww[0] * d.inv_env[i0], ww[1] * d.inv_env[i1]);
-    }
-
-    // per-lane state: the 4 bin pairs (k, 512-k), k = lane + 64 t, plus bin 256 (meaningful in lane 0)
-    float mlo[4], mhi[4], mmid;
-    v2f alo[4], ahi[4], amid, plo[4], phi[4], pmid;
-    {
-        const size_t row = (b * 3 + w) * kBins;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int k = lane + 64 * t, kh = 512 - k;
-            mlo[t] = FROM_MEL ? lmag[w * 520 + k] : (mag != nullptr ? mag[row + k] : 1.0f);
-            mhi[t] = FROM_MEL ? lmag[w * 520 + kh] : (mag != nullptr ? mag[row + kh] : 1.0f);
-            alo[t] = init != nullptr ? init[row + k] : rand_angle(seed, sid0 + b, w, k);
-            ahi[t] = init != nullptr ? init[row + kh] : rand_angle(seed, sid0 + b, w, kh);
-            plo[t] = mk2(0.0f, 0.0f);
-            phi[t] = mk2(0.0f, 0.0f);
-        }
-        mmid = FROM_MEL ? lmag[w * 520 + 256] : (mag != nullptr ? mag[row + 256] : 1.0f);
-        amid = init != nullptr ? init[row + 256] : rand_angle(seed, sid0 + b, w, 256);
-        pmid = mk2(0.0f, 0.0f);
-    }
-
-    // a = rebuilt - m * tprev; tprev = rebuilt; angles = a / (|a| + 1e-16)   (v_sqrt / v_rcp: 1 ulp)
-    auto update = [mom](v2f reb, v2f& prev, v2f& ang) {
-        const v2f a = reb - prev * mom;
-        prev = reb;
-        const float inv = __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(fmaf(a[0], a[0], a[1] * a[1])) + 1e-16f);
-        ang = a * inv;
-    };
-
-    if (FROM_MEL) __syncthreads();        // the prologue scratch becomes the overlap-add lines
-
-    v2f v[8], xlo[4], xhi[4], xmid;
-    for (int it = 0;; ++it) {
-        // ---- istft of angles * magnitude: Hermitian merge, inverse FFT, synthesis window, overlap-add lines
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            xlo[t] = alo[t] * mlo[t];
-            xhi[t] = ahi[t] * mhi[t];
-        }
-        xmid = amid * mmid;
-        irfft_merge_pairs(xlo, xhi, xmid, wkh, lane, v);
-        fft512<true>(v, tw, mytile, lane);
-        float* y1 = ybuf[it & 1][0];
-        float* yo = ybuf[it & 1][1];
-        {
-            // column 1 -> y1[n]; column 0 keeps its second half -> yo[n-512]; column 2 its first half -> yo[n+512]
-            // (the other halves fall outside the samples the istft trim keeps and are simply not stored)
-            float* ydst = w == 1 ? y1 : (w == 0 ? yo - 512 : yo + 512);
-            const int t_lo = w == 0 ? 4 : 0, t_hi = w == 2 ? 4 : 8;
-#pragma unroll
-            for (int t = 0; t < 8; ++t)
-                if (t >= t_lo && t < t_hi) *reinterpret_cast<v2f*>(ydst + 2 * (lane + 64 * t)) = v[t] * wsyn[t];
-        }
-        __syncthreads();
-        if (it == n_iter) {
-            // final istft: divide by the window envelope, trim, scale (app3.py:217 `* peak`)
-            const float sc = scale != nullptr ? scale[b] : 1.0f;
-            for (int n = tid; n < kNR; n += kGlThreads)
-                wave[b * kNR + n] = (y1[n] + yo[n]) * d.inv_env[n] * sc;
-            break;
-        }
-        // ---- stft of the rebuilt signal (centre, reflect): this wave's column, analysis window
-#pragma unroll
-        for (int t = 0; t < 8; ++t)
-            v[t] = mk2(y1[src0[t]] + yo[src0[t]], y1[src1[t]] + yo[src1[t]]) * cw[t];
-        fft512<false>(v, tw, mytile, lane);
-        rfft_split_pairs(v, wkh, lane, xlo, xhi, xmid);
-        // ---- phase update with momentum
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            update(xlo[t], plo[t], alo[t]);
-            update(xhi[t], phi[t], ahi[t]);
-        }
-        update(xmid, pmid, amid);
-    }
+    __shared__ __attribute__((aligned(16))) char smem[kGlSmem];
+    gl_body<FROM_MEL>(smem, d, mag, diff, init, seed, sid0, scale, wave, n_iter, mom, blockIdx.x, threadIdx.x);
 }
 
 void launch_griffinlim(const DspDev& d, const float* mag, const float* init, uint64_t seed, uint64_t sid0,

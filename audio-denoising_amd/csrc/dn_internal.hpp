@@ -40,6 +40,16 @@ void launch_synthesis(const DspDev& d, const float* x, const float* diff, const 
                       const float* scale, float* wave, int B, int n_iter, float momentum, hipStream_t st);
 void launch_cell(const CellDev& c, const float* x, const float* hx_in, float* out, float* hx_out, int B, int T,
                  int C, hipStream_t st);
+// Arguments of the software-pipelined hop launch (dn_hop.hip).
+struct HopArgs {
+    // front half: this hop's analysis + model + inverse mel, writing one scratch slot
+    const float* frames; float* hx; float* mel; float* diff; float* peak; float* lin;
+    // back half: the previous hop's Griffin-Lim, reading the other slot
+    const float* gl_lin; const float* gl_peak; const float* gl_init; uint64_t gl_seed, gl_sid0; float* gl_out;
+    int n_iter; float mom;
+    int front_B, back_B, C;
+};
+void launch_hop(const DspDev& d, const CellDev& c, const HopArgs& a, hipStream_t st);
 void launch_stream_shift(const float* hop_in, float* ring, int B, hipStream_t st);
 void launch_stream_ola(const float* y, float* ola, float* hop_out, int B, hipStream_t st);
 

@@ -5,110 +5,16 @@
 // reflect-padded n_fft-sample input produces.  The frame is read from HBM once (float4,
 // coalesced), lives in LDS, and only the 3 x n_mels log-mel values (or the 3 x 513 complex
 // bins for the plain Spectrogram entry point) go back to HBM.
-#include "dn_internal.hpp"
-#include "dn_wavefft.hpp"
+#include "dn_stft_body.hpp"
 
 namespace dn {
-
-constexpr int kStftThreads = 192;
-
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
-    return v;
-}
 
 template <bool WRITE_SPEC, bool WRITE_MEL>
 __global__ __launch_bounds__(kStftThreads) void stft_kernel(DspDev d, const float* __restrict__ frames,
                                                             float2* __restrict__ spec, float* __restrict__ mel,
                                                             float* __restrict__ peak_out, uint32_t flags) {
-    __shared__ float xs[kNR];
-    __shared__ v2f tile[3][kFftTile];
-    __shared__ float magbuf[3][kBins + 7];
-    __shared__ float red[3];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const size_t b = blockIdx.x;
-
-    // ---- P1: load the frame once, find max|x|
-    const float4* f4 = reinterpret_cast<const float4*>(frames + b * kNR);
-    float4 q0 = f4[tid];
-    float4 q1 = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool two = tid < (kNR / 4 - kStftThreads);
-    if (two) q1 = f4[tid + kStftThreads];
-    float mx = fmaxf(fmaxf(fabsf(q0.x), fabsf(q0.y)), fmaxf(fabsf(q0.z), fabsf(q0.w)));
-    mx = fmaxf(mx, fmaxf(fmaxf(fabsf(q1.x), fabsf(q1.y)), fmaxf(fabsf(q1.z), fabsf(q1.w))));
-    mx = wave_max(mx);
-    if (lane == 0) red[w] = mx;
-    __syncthreads();
-    float pk = fmaxf(red[0], fmaxf(red[1], red[2]));
-    const bool norm = (flags & DN_PEAK_NORMALIZE) && pk > 1e-6f;     // app3.py:182
-    if (!norm) pk = 1.0f;                                             // app3.py:186
-    if (peak_out != nullptr && tid == 0) peak_out[b] = pk;
-
-    // ---- P1/P2: x / peak, optional first Hann multiply (app3.py:183,188)
-    const float4* w4 = reinterpret_cast<const float4*>(d.window);
-    auto prep = [&](float4 q, int i4) {
-        if (norm) { q.x = q.x / pk; q.y = q.y / pk; q.z = q.z / pk; q.w = q.w / pk; }
-        if (flags & DN_PRE_WINDOW) {
-            float4 ww = w4[i4];
-            q.x *= ww.x; q.y *= ww.y; q.z *= ww.z; q.w *= ww.w;
-        }
-        reinterpret_cast<float4*>(xs)[i4] = q;
-    };
-    prep(q0, tid);
-    if (two) prep(q1, tid + kStftThreads);
-    __syncthreads();
-
-    // ---- P4: column w of the centred STFT: padded position p = 512 w + n, source i = p - 512 reflected
-    FftTwiddles tw;
-    load_twiddles(tw, d.tw512, lane);
-    v2f wkh[4], v[8];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) wkh[t] = cscale(reinterpret_cast<const v2f*>(d.tw1024)[lane + 64 * t], 0.5f);
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        const int m = lane + 64 * t;
-        const int n0 = 2 * m;
-        int i0 = w * 512 + n0 - 512, i1 = i0 + 1;
-        i0 = i0 < 0 ? -i0 : (i0 >= kNR ? 2 * kNR - 2 - i0 : i0);
-        i1 = i1 < 0 ? -i1 : (i1 >= kNR ? 2 * kNR - 2 - i1 : i1);
-        const v2f ww = reinterpret_cast<const v2f*>(d.window)[m];
-        v[t] = mk2(xs[i0] * ww[0], xs[i1] * ww[1]);
-    }
-    fft512<false>(v, tw, tile[w], lane);
-    // Hermitian split in pair order: this lane gets bins k = lane + 64 t and 512 - k (t < 4); lane 0 also bin 256
-    v2f lo[4], hi[4], mid;
-    rfft_split_pairs(v, wkh, lane, lo, hi, mid);
-
-    if (WRITE_SPEC) {
-        v2f* srow = reinterpret_cast<v2f*>(spec) + (b * 3 + w) * kBins;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            srow[lane + 64 * t] = lo[t];
-            srow[512 - (lane + 64 * t)] = hi[t];
-        }
-        if (lane == 0) srow[256] = mid;
-    }
-    if (WRITE_MEL) {
-        // ---- P5: magnitude -> banded mel filterbank -> log1p; P6: rows are already (B,3,M)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            magbuf[w][lane + 64 * t] = hypotf(lo[t][0], lo[t][1]);
-            magbuf[w][512 - (lane + 64 * t)] = hypotf(hi[t][0], hi[t][1]);
-        }
-        if (lane == 0) magbuf[w][256] = hypotf(mid[0], mid[1]);
-        wave_sync();
-        float* mrow = mel + (b * 3 + w) * d.n_mels;
-        for (int m = lane; m < d.n_mels; m += 64) {
-            const int s = d.mel_start[m], len = d.mel_len[m];
-            float acc = 0.0f;
-            for (int i = 0; i < len; ++i) acc = fmaf(d.mel_w[i * d.n_mels + m], magbuf[w][s + i], acc);
-            mrow[m] = log1pf(acc);
-        }
-    }
+    __shared__ __attribute__((aligned(16))) char smem[kStftSmem];
+    stft_body<WRITE_SPEC, WRITE_MEL>(smem, d, frames, spec, mel, peak_out, flags, blockIdx.x, threadIdx.x);
 }
 
 // MelScale alone (app3.py:193 without the log): one wavefront per (b,t) row.

@@ -103,11 +103,11 @@ class Denoiser:
 
 
 class HopPipeline:
-    """Two-stream overlap of consecutive hops (``dn_pipe_*``): hop n's synthesis (inverse mel + Griffin-Lim, ~3/4
-    of a hop) runs on one internal HIP stream while hop n+1's analysis + GRUUNet2 run on another; ``hx`` is the only
-    dependency between hops and stays ordered on the front stream.  ``submit`` enqueues one hop for the whole batch;
-    ``flush`` makes the caller's current stream wait for everything submitted.  ``frames``/``out``/``hx`` must not be
-    touched between a submit and the flush that covers it."""
+    """Software-pipelined hops (``dn_pipe_*``): one launch per hop carries hop n's Griffin-Lim workgroups next to
+    hop n+1's analysis + GRUUNet2 + inverse-mel workgroups; ``hx`` is the only dependency between hops.
+    ``submit`` enqueues one hop for the whole batch on the current stream; the output of a hop is complete (in
+    stream order) after the next ``submit`` or ``flush``.  ``frames``/``out``/``hx``/``init_angles`` must not be
+    touched until then."""
 
     def __init__(self, denoiser: "Denoiser", batch: int):
         import weakref
@@ -118,13 +118,14 @@ class HopPipeline:
         with torch.cuda.device(denoiser.device):
             self.lib.check(self.lib.dn_pipe_create(self._model_handle, denoiser.plan.handle, batch, C.byref(handle)))
         self.handle = handle
+        self._keep = (None, None)
         self._fin = weakref.finalize(self, self.lib.dn_pipe_destroy, handle)
 
     def submit(self, frames: torch.Tensor, hx: torch.Tensor, out: torch.Tensor, seed: int = 0, stream_id0: int = 0,
                init_angles: torch.Tensor | None = None) -> None:
         d = self.dn
         keep, ia_ptr = d._angles_ptr(init_angles, self.batch)
-        self._keep = keep
+        self._keep = (self._keep[1], keep)      # this hop's and the previous hop's phases stay alive
         st = C.c_void_p(torch.cuda.current_stream(d.device).cuda_stream)
         self.lib.check(self.lib.dn_pipe_submit(self.handle, frames.data_ptr(), hx.data_ptr(), out.data_ptr(), ia_ptr, seed, stream_id0,
                                                d.n_iter, d.momentum, st))

@@ -24,7 +24,7 @@
  *   dn_istft                            server.py:174,216 InverseSpectrogram
  *   dn_process_frame                    app3.py:178-217  the whole per-hop loop body for B streams
  *   dn_stream_step                      app3.py:178-226  the same plus ring buffer / overlap-add state (P12)
- *   dn_pipe_*                           app3.py:178-217  the same hop, consecutive hops overlapped on two HIP streams
+ *   dn_pipe_*                           app3.py:178-217  the same hop, consecutive hops software-pipelined in one launch per hop
  *
  * Memory layouts (row-major, fp32; "complex" = interleaved re,im float pairs):
  *   frames      [B][n_fft]
@@ -165,14 +165,14 @@ int dn_stream_step(const dn_model* m, const dn_dsp* d, const float* hop_in, floa
                    float* hop_out, const float* init_angles, uint64_t seed, uint64_t stream_id0, int32_t n_iter,
                    float momentum, void* workspace, int32_t B, void* stream);
 
-/* ---- Two-stream hop pipeline -------------------------------------------------------------------------
- * Consecutive hops depend on each other only through hx (the model); hop n's synthesis (P8-P12, ~3/4 of
- * the time) is independent of hop n+1's analysis + model (P1-P7).  A dn_pipe owns two internal HIP streams,
- * events and double-buffered scratch and overlaps them: submit(n+1) runs its analysis + model on the front
- * stream while the back stream is still in hop n's Griffin-Lim.  Per call the work is ordered AFTER
- * everything already enqueued on `stream` (the caller's stream); results are ordered before whatever the
- * caller enqueues after dn_pipe_flush(pipe, stream).  `frames`, `out` and `hx` must not be touched by the
- * caller between a submit and the flush that covers it (hx is advanced in place, hop by hop). */
+/* ---- Software-pipelined hops ------------------------------------------------------------------------
+ * Consecutive hops depend on each other only through hx (the model); hop n's Griffin-Lim (~3/4 of a hop) is
+ * independent of hop n+1's analysis + model + inverse mel.  A dn_pipe overlaps them inside ONE launch per hop:
+ * dn_pipe_submit(hop n+1) launches a grid whose first B workgroups run hop n's Griffin-Lim and whose next B run
+ * hop n+1's P1-P10 (double-buffered scratch); dn_pipe_flush launches the last pending Griffin-Lim.  Everything is
+ * enqueued on `stream`; the output of a submitted hop is complete (in stream order) after the NEXT submit or the
+ * flush.  `frames`, `hx`, `out` and `init_angles` of a submit must stay valid and untouched until then (hx is
+ * advanced in place, hop by hop). */
 typedef struct dn_pipe dn_pipe;
 int dn_pipe_create(const dn_model* m, const dn_dsp* d, int32_t B, dn_pipe** out);
 void dn_pipe_destroy(dn_pipe* p);
