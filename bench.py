@@ -11,8 +11,8 @@ from step to step.  Streams are independent, so N GPUs run N x 256 streams with 
 (weak scaling); the only collectives are the barriers and the MAX of the elapsed time.
 
 Besides the contract fields the JSON line carries
-  roofline     -- the dominant kernel (griffinlim_kernel): algorithmic FLOPs per launch / its average launch
-                  duration measured with HIP events in this process, against the fp32 compute peak;
+  roofline     -- the dominant kernel (hop_kernel: one launch = one hop of the batch): algorithmic FLOPs per launch /
+                  its average launch duration measured with HIP events in this process, against the fp32 compute peak;
   cpu_baseline -- the CPU oracle (the reference's op sequence restated on torch-CPU, oracle/pipeline_ref.py)
                   timed on this host's cores on a bounded sample of the same workload (rank 0, N = 1 only).
 """
@@ -160,8 +160,8 @@ def main():
     hx = dn.init_hx(B)
     out = torch.empty_like(frames)
 
-    # Product configuration for throughput: consecutive hops overlapped on two HIP streams (dn_pipe_*): hop n's
-    # synthesis runs beside hop n+1's analysis + model; hx is the only inter-hop dependency and stays ordered.
+    # Product configuration for throughput: software-pipelined hops (dn_pipe_*): ONE launch per hop whose workgroups are
+    # hop n's Griffin-Lim next to hop n+1's analysis + model + inverse mel; hx is the only inter-hop dependency.
     from audio_denoising_amd.pipeline import HopPipeline
     pipe = None if args.serial else HopPipeline(dn, B)
 
@@ -207,12 +207,33 @@ def main():
         torch.cuda.synchronize()
         serial_ms = 1e3 * (time.perf_counter() - ts) / args.steps
         kt = staged_kernel_times(dn, frames, hx, min(args.steps, 100))
-        gl_s = kt["synthesis"] * 1e-3
-        ach = GL_FLOP_PER_FRAME * B / gl_s / 1e12
+        # dominant kernel of the timed region: hop_kernel.  Mean launch duration from HIP events recorded on the launch
+        # stream around each of 100 further pipelined hops (each launch = one whole hop of work for the batch).
+        if pipe is not None:
+            n_ev = min(args.steps, 100)
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_ev + 1)]
+            pipe.submit(frames, hx, out, seed=1, stream_id0=lo)
+            evs[0].record()
+            for i in range(n_ev):
+                pipe.submit(frames, hx, out, seed=2 + i, stream_id0=lo)
+                evs[i + 1].record()
+            pipe.flush()
+            torch.cuda.synchronize()
+            dom_ms = sum(evs[i].elapsed_time(evs[i + 1]) for i in range(n_ev)) / n_ev
+            dom_name, dom_flop = "hop_kernel (hop n Griffin-Lim blocks + hop n+1 analysis/model/inverse-mel blocks)", TOTAL_FLOP_PER_FRAME
+            dom_note = ("fp32 compute roof (FFT butterflies on the fp32 VALU, convs on fp32 MFMA; vector and matrix fp32 peaks are both 157.3 TF); "
+                        "algorithmic = 6.50 MFLOP per frame (198 rFFT-1024 x 25,600 + mel + convs + inverse mel) x 256 frames per launch")
+            dom_bytes = HBM_BYTES_PER_FRAME
+        else:
+            dom_ms, dom_name, dom_flop = kt["synthesis"], "griffinlim_kernel<from mel> (P8-P12)", GL_FLOP_PER_FRAME
+            dom_note = "fp32 compute roof; algorithmic = (195 rFFT-1024 x 25,600 + 246,240 inverse-mel) flop per frame x 256 frames per launch"
+            dom_bytes = GL_HBM_BYTES_PER_FRAME
+        gl_s = dom_ms * 1e-3
+        ach = dom_flop * B / gl_s / 1e12
         traffic = None
         pmc = os.path.join(REPO, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
-            traffic = json.load(open(pmc)).get("griffinlim_kernel_hbm_bytes_per_launch")
+            traffic = json.load(open(pmc)).get("hop_kernel_hbm_bytes_per_launch" if pipe is not None else "griffinlim_kernel_hbm_bytes_per_launch")
         line = {
             "metric": "denoised audio frames/sec (32 ms, 16 kHz, hop 512) at batch 256; 1/2/4/8 GPU",
             "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -222,14 +243,12 @@ def main():
                                    "(dari_tult weights, num_compressed_bins=5), 32-iter Griffin-Lim, device-RNG initial phases, hx carried",
                        "streams_per_gpu": B, "frames_per_step": B * world, "sample_rate": SR, "n_fft": N_FFT, "hop": HOP,
                        "n_mels": N_MELS, "griffinlim_iters": GL_ITERS, "parallelism": f"stream-sharded x{world} (no data-path collective)"},
-            "roofline": {"bound": "mfma", "kernel": "griffinlim_kernel<from mel> (P8-P12: inverse mel + 32-iter Griffin-Lim)", "achieved": round(ach, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ach / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
-                         "note": "fp32 compute roof (FFT butterflies on the fp32 VALU; vector and matrix fp32 peaks are both 157.3 TF); "
-                                 "algorithmic = (195 rFFT-1024 x 25,600 + 246,240 inverse-mel) flop per frame x 256 frames per launch",
-                         "launch_ms": round(kt["synthesis"], 4),
-                         "hbm_frac": round(GL_HBM_BYTES_PER_FRAME * B / gl_s / 1e9 / PEAK_HBM_GBS, 6)},
+            "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": round(ach, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(ach / PEAK_FP32_TFLOPS, 4), "traffic": traffic, "note": dom_note,
+                         "launch_ms": round(dom_ms, 4),
+                         "hbm_frac": round(dom_bytes * B / gl_s / 1e9 / PEAK_HBM_GBS, 6)},
             "kernel_ms": {k: round(v, 4) for k, v in kt.items()},
-            "schedule": "serial (dn_process_frame)" if pipe is None else "two-stream hop pipeline (dn_pipe_submit)",
+            "schedule": "serial, 3 launches per hop (dn_process_frame)" if pipe is None else "software-pipelined, 1 launch per hop (dn_pipe_submit)",
             "serial_ms_per_step": round(serial_ms, 4),
             "whole_path": {"tflops": round(TOTAL_FLOP_PER_FRAME * value / 1e12, 3),
                            "fp32_frac": round(TOTAL_FLOP_PER_FRAME * value / 1e12 / (PEAK_FP32_TFLOPS * world), 4),

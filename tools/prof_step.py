@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Profiling driver: a few fused hops at batch 256 (same workload as bench.py), nothing else.
+"""Profiling driver: a few hops at batch 256 (same workload and schedule as bench.py), nothing else.
+    python tools/prof_step.py [steps] [batch] [serial]
 Run under rocprofv3 (--kernel-trace --stats, or a --pmc pass) from the repo root."""
 import os
 import sys
@@ -19,8 +20,15 @@ def main():
     frames = (0.1 * torch.randn(batch, bench.N_FFT, generator=g)).to(dev)
     hx = dn.init_hx(batch)
     out = torch.empty_like(frames)
-    for i in range(steps):
-        dn.process_frame_(frames, hx, out, seed=1000 + i, stream_id0=0)
+    if len(sys.argv) > 3 and sys.argv[3] == "serial":
+        for i in range(steps):
+            dn.process_frame_(frames, hx, out, seed=1000 + i, stream_id0=0)
+    else:
+        from audio_denoising_amd.pipeline import HopPipeline
+        pipe = HopPipeline(dn, batch)
+        for i in range(steps):
+            pipe.submit(frames, hx, out, seed=1000 + i, stream_id0=0)
+        pipe.flush()
     torch.cuda.synchronize()
     print("ok", float(out.abs().mean()))
 
