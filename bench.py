@@ -143,12 +143,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hop path has no CPU fallback")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    n_dev = torch.cuda.device_count()
+    dev = torch.device("cuda", local % n_dev)          # one rank per GPU; (rehearsals on a 1-GPU box share cuda:0)
+    torch.cuda.set_device(dev)
     dist = None
+    backend = os.environ.get("DN_DIST_BACKEND", "nccl")   # "nccl" = RCCL over xGMI; "gloo" only to rehearse the rank plumbing
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from audio_denoising_amd.shard import shard_range
@@ -176,7 +181,7 @@ def main():
             pipe.flush()
         torch.cuda.synchronize()
         if dist is not None:
-            dist.barrier()
+            dist.barrier(device_ids=[dev.index]) if backend == "nccl" else dist.barrier()
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
@@ -188,7 +193,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert torch.isfinite(out).all()
@@ -257,7 +262,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
     if dist is not None:
-        dist.barrier()
+        dist.barrier(device_ids=[dev.index]) if backend == "nccl" else dist.barrier()
         dist.destroy_process_group()
     if line is not None:
         print(json.dumps(line), flush=True)
