@@ -19,7 +19,8 @@ SYMBOLS = (
     "dn_model_create", "dn_model_destroy", "dn_cell_forward", "dn_dsp_create", "dn_dsp_destroy",
     "dn_dsp_get_tables", "dn_stft", "dn_stft_mel_log1p", "dn_mel_scale", "dn_invmel", "dn_residual_invmel",
     "dn_griffinlim", "dn_synthesis", "dn_istft", "dn_workspace_bytes", "dn_process_frame", "dn_stream_step",
-    "dn_pipe_create", "dn_pipe_destroy", "dn_pipe_submit", "dn_pipe_flush", "dn_last_error", "dn_abi_version",
+    "dn_pipe_create", "dn_pipe_destroy", "dn_pipe_submit", "dn_pipe_flush", "dn_pipe_stream_create", "dn_pipe_stream_push",
+    "dn_pipe_stream_flush", "dn_pipe_stream_get_state", "dn_pipe_stream_set_state", "dn_last_error", "dn_abi_version",
 )
 
 DN_PEAK_NORMALIZE = 1
@@ -81,6 +82,11 @@ class DnLib:
         L.dn_pipe_destroy.restype = None
         L.dn_pipe_submit.argtypes = [vp, p, p, p, p, u64, u64, i32, f32, vp]
         L.dn_pipe_flush.argtypes = [vp, vp]
+        L.dn_pipe_stream_create.argtypes = [vp, vp, i32, C.POINTER(vp)]
+        L.dn_pipe_stream_push.argtypes = [vp, p, i32, p, i32, p, u64, u64, i32, f32, vp]
+        L.dn_pipe_stream_flush.argtypes = [vp, p, i32, vp]
+        L.dn_pipe_stream_get_state.argtypes = [vp, p, p, p, vp]
+        L.dn_pipe_stream_set_state.argtypes = [vp, p, p, p, vp]
         if L.dn_abi_version() != ABI_VERSION:
             raise ImportError(f"{path}: ABI version {L.dn_abi_version()} != {ABI_VERSION}; rebuild the extension")
 

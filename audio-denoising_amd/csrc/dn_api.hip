@@ -133,6 +133,11 @@ struct dn_pipe {
     BiasSet* bs = nullptr;
     bool pending = false;                     // a hop whose Griffin-Lim has not been launched yet
     dn::HopArgs last{};                       // its back-half arguments
+    // streaming mode: per-stream state owned by the pipe
+    float* ring = nullptr;                    // [B][n_fft] last n_fft input samples
+    float* ola = nullptr;                     // [B][n_fft] output overlap-add line
+    float* hx = nullptr;                      // [B][17][C]
+    uint64_t pushes = 0;
 };
 
 namespace {
@@ -604,7 +609,98 @@ void dn_pipe_destroy(dn_pipe* p) {
     if (!p) return;
     for (int i = 0; i < 2; ++i)
         if (p->scratch[i]) (void)hipFree(p->scratch[i]);
+    if (p->ring) (void)hipFree(p->ring);
+    if (p->ola) (void)hipFree(p->ola);
+    if (p->hx) (void)hipFree(p->hx);
     delete p;
+}
+
+int dn_pipe_stream_create(const dn_model* m, const dn_dsp* d, int32_t B, dn_pipe** out) {
+    dn_pipe* p = nullptr;
+    int rc = dn_pipe_create(m, d, B, &p);
+    if (rc != DN_OK) return rc;
+    const size_t line = (size_t)B * d->cfg.n_fft * sizeof(float), hxb = (size_t)B * dn::kHidden * p->C * sizeof(float);
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&p->ring), line);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->ola), line);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->hx), hxb);
+    if (e == hipSuccess) e = hipMemset(p->ring, 0, line);
+    if (e == hipSuccess) e = hipMemset(p->ola, 0, line);
+    if (e == hipSuccess) e = hipMemset(p->hx, 0, hxb);
+    if (e != hipSuccess) { dn_pipe_destroy(p); return fail(DN_ERR_HIP, std::string("dn_pipe_stream_create: ") + hipGetErrorString(e)); }
+    *out = p;
+    return DN_OK;
+}
+
+static int stream_state_copy(dn_pipe* p, float* ring, float* ola, float* hx, bool to_pipe, void* stream) {
+    if (!p || !p->ring) return fail(DN_ERR_INVALID, "not a streaming pipe");
+    const size_t line = (size_t)p->B * p->d->cfg.n_fft * sizeof(float), hxb = (size_t)p->B * dn::kHidden * p->C * sizeof(float);
+    hipStream_t st = as_stream(stream);
+    if (ring) DN_HIP(hipMemcpyAsync(to_pipe ? p->ring : ring, to_pipe ? ring : p->ring, line, hipMemcpyDeviceToDevice, st));
+    if (ola) DN_HIP(hipMemcpyAsync(to_pipe ? p->ola : ola, to_pipe ? ola : p->ola, line, hipMemcpyDeviceToDevice, st));
+    if (hx) DN_HIP(hipMemcpyAsync(to_pipe ? p->hx : hx, to_pipe ? hx : p->hx, hxb, hipMemcpyDeviceToDevice, st));
+    return DN_OK;
+}
+
+int dn_pipe_stream_get_state(dn_pipe* p, float* ring, float* ola, float* hx, void* stream) {
+    return stream_state_copy(p, ring, ola, hx, false, stream);
+}
+
+int dn_pipe_stream_set_state(dn_pipe* p, const float* ring, const float* ola, const float* hx, void* stream) {
+    if (p && p->pending) return fail(DN_ERR_INVALID, "dn_pipe_stream_set_state: flush the pending hop first");
+    int rc = stream_state_copy(p, const_cast<float*>(ring), const_cast<float*>(ola), const_cast<float*>(hx), true, stream);
+    if (rc == DN_OK && ring) p->pushes = (uint64_t)(p->d->cfg.n_fft / p->d->cfg.hop - 1);   // a restored ring is a primed ring
+    return rc;
+}
+
+int dn_pipe_stream_push(dn_pipe* p, const void* hop_in, int32_t in_is_s16, void* hop_out, int32_t out_is_s16,
+                        const float* init_angles, uint64_t seed, uint64_t stream_id0, int32_t n_iter, float momentum, void* stream) {
+    if (!p || !p->ring) return fail(DN_ERR_INVALID, "dn_pipe_stream_push: not a streaming pipe");
+    if (!hop_in || !hop_out) return fail(DN_ERR_INVALID, "dn_pipe_stream_push: null argument");
+    if (n_iter < 0) return fail(DN_ERR_INVALID, "dn_pipe_stream_push: negative n_iter");
+    if (!(momentum >= 0.0f && momentum < 1.0f)) return fail(DN_ERR_INVALID, "momentum must be in [0, 1)");
+    const int B = p->B, M = p->d->cfg.n_mels, hop = p->d->cfg.hop;
+    const uint64_t prime = (uint64_t)(p->d->cfg.n_fft / hop - 1);       // pushes that only fill the ring
+    const bool priming = p->pushes < prime;
+    dn::HopArgs a = p->last;                       // back half: the frame submitted by the previous push (if any)
+    a.back_B = p->pending ? B : 0;
+    a.ola = p->ola; a.hop_out = hop_out; a.out_s16 = out_is_s16;
+    if (!p->pending)                               // nothing is emitted yet: the reference's ola[:hop] is still zero
+        DN_HIP(hipMemsetAsync(hop_out, 0, (size_t)B * hop * (out_is_s16 ? 2 : 4), as_stream(stream)));
+    const int s = (int)(p->seq & 1);
+    a.frames = nullptr; a.hx = p->hx;
+    a.mel = p->scratch[s];
+    a.diff = a.mel + (size_t)B * 3 * M;
+    a.peak = a.diff + (size_t)B * 3 * M;
+    a.lin = a.peak + B;
+    a.front_B = B; a.C = p->C;
+    a.hop_in = hop_in; a.ring = p->ring; a.in_s16 = in_is_s16; a.prime_only = priming ? 1 : 0;
+    dn::launch_hop(p->d->view, p->bs->view, a, as_stream(stream));
+    int rc = check_launch("hop_kernel(stream)");
+    if (rc != DN_OK) return rc;
+    p->pushes++;
+    if (priming) { p->pending = false; return DN_OK; }
+    p->last.gl_lin = a.lin; p->last.gl_peak = a.peak; p->last.gl_init = init_angles;
+    p->last.gl_seed = seed; p->last.gl_sid0 = stream_id0; p->last.gl_out = nullptr;
+    p->last.n_iter = n_iter; p->last.mom = momentum / (1.0f + momentum);
+    p->pending = true;
+    p->seq++;
+    return DN_OK;
+}
+
+int dn_pipe_stream_flush(dn_pipe* p, void* hop_out, int32_t out_is_s16, void* stream) {
+    if (!p || !p->ring) return fail(DN_ERR_INVALID, "dn_pipe_stream_flush: not a streaming pipe");
+    if (!hop_out) return fail(DN_ERR_INVALID, "dn_pipe_stream_flush: null argument");
+    if (!p->pending) {
+        DN_HIP(hipMemsetAsync(hop_out, 0, (size_t)p->B * p->d->cfg.hop * (out_is_s16 ? 2 : 4), as_stream(stream)));
+        return DN_OK;
+    }
+    dn::HopArgs a = p->last;
+    a.back_B = p->B; a.front_B = 0; a.C = p->C;
+    a.ola = p->ola; a.hop_out = hop_out; a.out_s16 = out_is_s16;
+    a.ring = nullptr; a.hop_in = nullptr;
+    dn::launch_hop(p->d->view, p->bs->view, a, as_stream(stream));
+    p->pending = false;
+    return check_launch("hop_kernel(stream flush)");
 }
 
 int dn_pipe_submit(dn_pipe* p, const float* frames, float* hx, float* out, const float* init_angles, uint64_t seed,
@@ -621,6 +717,7 @@ int dn_pipe_submit(dn_pipe* p, const float* frames, float* hx, float* out, const
     a.peak = a.diff + (size_t)B * 3 * M;
     a.lin = a.peak + B;
     a.front_B = B; a.C = p->C;
+    a.ring = nullptr; a.hop_in = nullptr; a.ola = nullptr; a.hop_out = nullptr; a.prime_only = 0;
     dn::launch_hop(p->d->view, p->bs->view, a, as_stream(stream));
     int rc = check_launch("hop_kernel");
     if (rc != DN_OK) return rc;
@@ -639,6 +736,7 @@ int dn_pipe_flush(dn_pipe* p, void* stream) {
     dn::HopArgs a = p->last;
     a.back_B = p->B; a.front_B = 0; a.C = p->C;
     a.frames = nullptr; a.hx = nullptr; a.mel = nullptr; a.diff = nullptr; a.peak = nullptr; a.lin = nullptr;
+    a.ring = nullptr; a.hop_in = nullptr; a.ola = nullptr; a.hop_out = nullptr; a.prime_only = 0;
     dn::launch_hop(p->d->view, p->bs->view, a, as_stream(stream));
     p->pending = false;
     return check_launch("hop_kernel(flush)");

@@ -36,11 +36,14 @@ __device__ __forceinline__ v2f rand_angle(uint64_t seed, uint64_t sid, int col, 
 constexpr int kGlSmem = 8 * 3 * kFftTile + 4 * 2 * 2 * kNR;      // 30,208 B
 
 // One workgroup (192 threads = 3 wavefronts = 3 columns) runs all iterations for stream `b`.  `smem`: kGlSmem bytes.
-template <bool FROM_MEL>
+// STREAM = true: instead of storing the frame, fold it into the stream's overlap-add line (P12, app3.py:219-224):
+//   hop_out <- ola[:hop] (float, or clipped int16 as app3.py:244-245); ola <- concat(ola[hop:], 0) + frame.
+template <bool FROM_MEL, bool STREAM = false>
 __device__ __forceinline__ void gl_body(char* smem, const DspDev& d, const float* __restrict__ mag,
                                         const float* __restrict__ diff, const v2f* __restrict__ init, uint64_t seed,
                                         uint64_t sid0, const float* __restrict__ scale, float* __restrict__ wave,
-                                        int n_iter, float mom, size_t b, int tid) {
+                                        int n_iter, float mom, size_t b, int tid, float* ola = nullptr,
+                                        void* hop_out = nullptr, int out_s16 = 0) {
     v2f (*tile)[kFftTile] = reinterpret_cast<v2f (*)[kFftTile]>(smem);
     // [ping-pong][0: centre column, 1: halves of columns 0 and 2][n]
     float (*ybuf)[2][kNR] = reinterpret_cast<float (*)[2][kNR]>(smem + 8 * 3 * kFftTile);
@@ -169,8 +172,36 @@ __device__ __forceinline__ void gl_body(char* smem, const DspDev& d, const float
         if (it == n_iter) {
             // final istft: divide by the window envelope, trim, scale (app3.py:217 `* peak`)
             const float sc = scale != nullptr ? scale[b] : 1.0f;
-            for (int n = tid; n < kNR; n += kGlThreads)
-                wave[b * kNR + n] = (y1[n] + yo[n]) * d.inv_env[n] * sc;
+            if (!STREAM) {
+                for (int n = tid; n < kNR; n += kGlThreads)
+                    wave[b * kNR + n] = (y1[n] + yo[n]) * d.inv_env[n] * sc;
+            } else {
+                constexpr int kR = (kNR + kGlThreads - 1) / kGlThreads;
+                float* orow = ola + b * kNR;
+                float cur[kR], nxt[kR];
+#pragma unroll
+                for (int r = 0; r < kR; ++r) {
+                    const int n = tid + kGlThreads * r;
+                    cur[r] = n < kNR ? orow[n] : 0.0f;
+                    nxt[r] = n + kNR / 2 < kNR ? orow[n + kNR / 2] : 0.0f;
+                }
+                __syncthreads();          // every old sample is in registers before the line is rewritten
+#pragma unroll
+                for (int r = 0; r < kR; ++r) {
+                    const int n = tid + kGlThreads * r;
+                    if (n < kNR) {
+                        orow[n] = nxt[r] + (y1[n] + yo[n]) * d.inv_env[n] * sc;
+                        if (n < kNR / 2) {
+                            if (out_s16) {
+                                const float c = fminf(fmaxf(cur[r], -1.0f), 1.0f) * 32767.0f;      // np.clip, * iinfo(int16).max
+                                static_cast<short*>(hop_out)[b * (kNR / 2) + n] = (short)c;          // astype(int16): truncation
+                            } else {
+                                static_cast<float*>(hop_out)[b * (kNR / 2) + n] = cur[r];
+                            }
+                        }
+                    }
+                }
+            }
             break;
         }
         // ---- stft of the rebuilt signal (centre, reflect): this wave's column, analysis window

@@ -28,11 +28,46 @@ __global__ __launch_bounds__(kHopThreads) void hop_kernel(DspDev d, CellDev cd, 
     __shared__ __attribute__((aligned(16))) char smem[kHopSmem];
     const int tid = threadIdx.x;
     if ((int)blockIdx.x < a.back_B) {
-        gl_body<false>(smem, d, a.gl_lin, nullptr, reinterpret_cast<const v2f*>(a.gl_init), a.gl_seed, a.gl_sid0, a.gl_peak,
-                       a.gl_out, a.n_iter, a.mom, blockIdx.x, tid);
+        if (a.ola == nullptr)
+            gl_body<false, false>(smem, d, a.gl_lin, nullptr, reinterpret_cast<const v2f*>(a.gl_init), a.gl_seed, a.gl_sid0,
+                                  a.gl_peak, a.gl_out, a.n_iter, a.mom, blockIdx.x, tid);
+        else
+            gl_body<false, true>(smem, d, a.gl_lin, nullptr, reinterpret_cast<const v2f*>(a.gl_init), a.gl_seed, a.gl_sid0,
+                                 a.gl_peak, nullptr, a.n_iter, a.mom, blockIdx.x, tid, a.ola, a.hop_out, a.out_s16);
     } else {
         const size_t b = blockIdx.x - a.back_B;
-        stft_body<false, true>(smem, d, a.frames, nullptr, a.mel, a.peak, DN_PEAK_NORMALIZE | DN_PRE_WINDOW, b, tid);   // P1-P6
+        const float* frames = a.frames;
+        if (a.ring != nullptr) {
+            // ring <- concat(ring[hop:], hop_in): every thread holds its float4s before anything is overwritten
+            constexpr int kLine4 = kNR / 4, kHop4 = kNR / 8;
+            float4* r4 = reinterpret_cast<float4*>(a.ring + b * kNR);
+            float4 v[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int i4 = tid + kHopThreads * r;
+                v[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i4 < kLine4 - kHop4) v[r] = r4[i4 + kHop4];
+                else if (i4 < kLine4) {
+                    const int j4 = i4 - (kLine4 - kHop4);
+                    if (a.in_s16) {      // int16 -> float32 / iinfo(int16).max   (app3.py:172)
+                        const short4 q = reinterpret_cast<const short4*>(static_cast<const short*>(a.hop_in) + b * (kNR / 2))[j4];
+                        v[r] = make_float4((float)q.x / 32767.0f, (float)q.y / 32767.0f, (float)q.z / 32767.0f, (float)q.w / 32767.0f);
+                    } else {
+                        v[r] = reinterpret_cast<const float4*>(static_cast<const float*>(a.hop_in) + b * (kNR / 2))[j4];
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int i4 = tid + kHopThreads * r;
+                if (i4 < kLine4) r4[i4] = v[r];
+            }
+            __syncthreads();
+            if (a.prime_only) return;
+            frames = a.ring;
+        }
+        stft_body<false, true>(smem, d, frames, nullptr, a.mel, a.peak, DN_PEAK_NORMALIZE | DN_PRE_WINDOW, b, tid);   // P1-P6
         __syncthreads();
         cell_body<kHopThreads / 64>(smem, cd, a.mel, a.hx, a.diff, a.hx, 3, a.C, b, tid);                               // P7
         __syncthreads();

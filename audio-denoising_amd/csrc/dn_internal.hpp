@@ -48,6 +48,10 @@ struct HopArgs {
     const float* gl_lin; const float* gl_peak; const float* gl_init; uint64_t gl_seed, gl_sid0; float* gl_out;
     int n_iter; float mom;
     int front_B, back_B, C;
+    // streaming mode (pipe-owned per-stream state): the front half first shifts `hop_in` into `ring` and uses the ring
+    // as its frame (app3.py:178,226); the back half folds its frame into `ola` and emits `hop_out` (app3.py:219-224)
+    const void* hop_in; float* ring; int in_s16; int prime_only;
+    float* ola; void* hop_out; int out_s16;
 };
 void launch_hop(const DspDev& d, const CellDev& c, const HopArgs& a, hipStream_t st);
 void launch_stream_shift(const float* hop_in, float* ring, int B, hipStream_t st);

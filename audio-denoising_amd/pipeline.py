@@ -135,6 +135,72 @@ class HopPipeline:
         self.lib.check(self.lib.dn_pipe_flush(self.handle, st))
 
 
+class PipelinedStream:
+    """B concurrent streams, state (ring, overlap-add line, hx) owned by the native pipe, ONE launch per hop
+    (``dn_pipe_stream_*``; BASELINE config 5).  ``push(hop)`` takes ``(B, hop_length)`` new samples (float32, or int16
+    PCM) and returns ``(B, hop_length)`` output samples in the same format.  Hops are software-pipelined, so the
+    samples the reference emits while processing frame f come out one push later (zeros until then);
+    ``flush()`` returns the last pending hop."""
+
+    def __init__(self, denoiser: "Denoiser", batch: int, stream_id0: int = 0, seed: int = 0):
+        import weakref
+        self.dn, self.batch, self.stream_id0, self.seed = denoiser, batch, stream_id0, seed
+        self.lib = denoiser.lib
+        handle = C.c_void_p()
+        self._model_handle = denoiser.model._native(denoiser.device)
+        with torch.cuda.device(denoiser.device):
+            self.lib.check(self.lib.dn_pipe_stream_create(self._model_handle, denoiser.plan.handle, batch, C.byref(handle)))
+        self.handle = handle
+        self._keep = (None, None)
+        self.pushes = 0
+        self._fin = weakref.finalize(self, self.lib.dn_pipe_destroy, handle)
+
+    def _out(self, like_s16: bool) -> torch.Tensor:
+        return torch.empty(self.batch, self.dn.hop, dtype=torch.int16 if like_s16 else torch.float32, device=self.dn.device)
+
+    def push(self, hop: torch.Tensor, init_angles: torch.Tensor | None = None) -> torch.Tensor:
+        d = self.dn
+        if hop.device != d.device or tuple(hop.shape) != (self.batch, d.hop) or hop.dtype not in (torch.float32, torch.int16) \
+                or not hop.is_contiguous():
+            raise ValueError(f"hop must be contiguous float32 or int16 of shape {(self.batch, d.hop)} on {d.device}")
+        s16 = hop.dtype == torch.int16
+        out = self._out(s16)
+        keep, ia_ptr = d._angles_ptr(init_angles, self.batch)
+        self._keep = (self._keep[1], (keep, hop))
+        with torch.cuda.device(d.device):
+            st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            self.lib.check(self.lib.dn_pipe_stream_push(self.handle, hop.data_ptr(), int(s16), out.data_ptr(), int(s16), ia_ptr,
+                                                        self.seed + self.pushes, self.stream_id0, d.n_iter, d.momentum, st))
+        self.pushes += 1
+        return out
+
+    def flush(self, s16: bool = False) -> torch.Tensor:
+        out = self._out(s16)
+        with torch.cuda.device(self.dn.device):
+            st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            self.lib.check(self.lib.dn_pipe_stream_flush(self.handle, out.data_ptr(), int(s16), st))
+        return out
+
+    def state(self):
+        """Snapshot (ring, ola, hx) of the pipe-owned stream state (checkpointing live streams)."""
+        d = self.dn
+        ring = torch.empty(self.batch, d.n_fft, dtype=torch.float32, device=d.device)
+        ola = torch.empty_like(ring)
+        hx = torch.empty(self.batch, d.model.latent_size, d.num_compressed_bins, dtype=torch.float32, device=d.device)
+        st = C.c_void_p(torch.cuda.current_stream(d.device).cuda_stream)
+        self.lib.check(self.lib.dn_pipe_stream_get_state(self.handle, ring.data_ptr(), ola.data_ptr(), hx.data_ptr(), st))
+        return ring, ola, hx
+
+    def load_state(self, ring: torch.Tensor, ola: torch.Tensor, hx: torch.Tensor) -> None:
+        """Resume streams from a snapshot taken with ``state()`` (after ``flush()``)."""
+        for t in (ring, ola, hx):
+            if t.device != self.dn.device or t.dtype != torch.float32 or not t.is_contiguous():
+                raise ValueError("state tensors must be contiguous float32 on the denoiser's device")
+        st = C.c_void_p(torch.cuda.current_stream(self.dn.device).cuda_stream)
+        self.lib.check(self.lib.dn_pipe_stream_set_state(self.handle, ring.data_ptr(), ola.data_ptr(), hx.data_ptr(), st))
+        self.pushes = max(self.pushes, self.dn.n_fft // self.dn.hop - 1)
+
+
 class DenoiserStream:
     """B concurrent streams with persistent device state: input ring, output overlap-add buffer, hx.
 

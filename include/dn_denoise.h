@@ -180,6 +180,26 @@ int dn_pipe_submit(dn_pipe* p, const float* frames, float* hx, float* out, const
                    uint64_t stream_id0, int32_t n_iter, float momentum, void* stream);
 int dn_pipe_flush(dn_pipe* p, void* stream);
 
+/* Streaming form (BASELINE config 5; app3.py:168-250 without the av container): the pipe owns the per-stream state
+ * (input ring, output overlap-add line, hx -- app3.py:130-133) in HBM and every push is ONE launch.
+ *   hop_in  [dev][B][hop]  float32 samples, or int16 PCM when in_is_s16 (converted as app3.py:172: x / 32767)
+ *   hop_out [dev][B][hop]  float32, or int16 when out_is_s16 (clip to [-1,1], * 32767, truncate: app3.py:244-245)
+ * The first n_fft/hop - 1 pushes only fill the ring.  Because hops are software-pipelined, the samples the reference
+ * would emit while processing frame f (ola[:hop] before frame f is added, app3.py:219-220) come out of the push
+ * that follows the one that delivered frame f's last hop -- one hop of extra latency; zeros until then.
+ * dn_pipe_stream_flush emits the last pending hop.  init_angles (NULL = device RNG) must stay valid until the next
+ * push/flush. */
+int dn_pipe_stream_create(const dn_model* m, const dn_dsp* d, int32_t B, dn_pipe** out);
+int dn_pipe_stream_push(dn_pipe* p, const void* hop_in, int32_t in_is_s16, void* hop_out, int32_t out_is_s16,
+                        const float* init_angles, uint64_t seed, uint64_t stream_id0, int32_t n_iter, float momentum,
+                        void* stream);
+int dn_pipe_stream_flush(dn_pipe* p, void* hop_out, int32_t out_is_s16, void* stream);
+/* Checkpoint / resume of live streams: copy the pipe-owned state out to / in from caller buffers [dev]
+ * (ring [B][n_fft], ola [B][n_fft], hx [B][17][C]; any may be NULL), ordered on `stream`.  set_state requires that no
+ * hop is pending (call dn_pipe_stream_flush first); a restored ring counts as primed. */
+int dn_pipe_stream_get_state(dn_pipe* p, float* ring, float* ola, float* hx, void* stream);
+int dn_pipe_stream_set_state(dn_pipe* p, const float* ring, const float* ola, const float* hx, void* stream);
+
 const char* dn_last_error(void);
 int dn_abi_version(void);
 

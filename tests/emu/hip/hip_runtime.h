@@ -48,6 +48,10 @@ inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n); return *p ? 0 
 inline hipError_t hipFree(void* p) { free(p); return 0; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return 0; }
 inline hipError_t hipGetLastError() { return 0; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return 0; }
+inline hipError_t hipMemset(void* p, int v, size_t n) { memset(p, v, n); return 0; }
+inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
+struct short4 { short x, y, z, w; };
 // streams and events: the emulation is synchronous, so these only have to exist
 typedef struct dn_emu_event* hipEvent_t;
 constexpr unsigned hipStreamNonBlocking = 1, hipEventDisableTiming = 2;

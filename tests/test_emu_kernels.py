@@ -197,3 +197,48 @@ def test_pipelined_hops_equal_serial_hops(lib, dsp):
     assert np.array_equal(hx_a, hx_b)
     for a, b in zip(outs_a, outs_b):
         assert np.abs(a - b).max() <= 1e-5      # fused-prologue vs separate inverse-mel launch differ only in summation order
+
+
+def test_streaming_pipe_matches_oracle_with_one_hop_delay(lib, dsp):
+    """dn_pipe_stream_*: ring shift, frame, overlap-add and emission inside the one-launch hop; float and int16 I/O."""
+    g = load_golden("stream_S.npz")
+    B, n_frames = 2, 3
+    sig, inits = g["signal"][:B], g["init_angles"][:, :B]
+    m = make_model(lib, 5)
+    pipe = C.c_void_p()
+    lib.check(lib.dn_pipe_stream_create(m, dsp, B, C.byref(pipe)))
+    outs, keep = [], []
+    for p_i in range(n_frames + 1):                      # push 0 primes the ring; push f+1 delivers frame f
+        hop_in = emu.f32(sig[:, p_i * P.hop:(p_i + 1) * P.hop])
+        ia = None
+        if p_i >= 1:
+            a = inits[p_i - 1].transpose(0, 2, 1)
+            ia = emu.f32(np.stack([a.real, a.imag], axis=-1))
+        keep.append((hop_in, ia))
+        out = np.full((B, P.hop), 7.0, np.float32)
+        lib.check(lib.dn_pipe_stream_push(pipe, emu.ptr(hop_in), 0, emu.ptr(out), 0, emu.ptr(ia), 0, 0, 32, 0.99, None))
+        outs.append(out)
+    last = np.zeros((B, P.hop), np.float32)
+    lib.check(lib.dn_pipe_stream_flush(pipe, emu.ptr(last), 0, None))
+    outs.append(last)
+    assert np.all(outs[0] == 0) and np.all(outs[1] == 0)                      # nothing to emit yet
+    got = np.concatenate(outs[2:], axis=1)                                    # segments of frames 0..n_frames-1
+    ref = g["out"][:B, :n_frames * P.hop]
+    assert np.sqrt(np.mean((got - ref) ** 2)) <= 1e-3
+    lib.dn_pipe_destroy(pipe)
+    # int16 in / int16 out: quantised input through the float path must give the same samples, quantised
+    pipe = C.c_void_p()
+    lib.check(lib.dn_pipe_stream_create(m, dsp, B, C.byref(pipe)))
+    pipe_f = C.c_void_p()
+    lib.check(lib.dn_pipe_stream_create(m, dsp, B, C.byref(pipe_f)))
+    for p_i in range(3):
+        q = np.clip(np.round(sig[:, p_i * P.hop:(p_i + 1) * P.hop] * 3.0 * 32767), -32768, 32767).astype(np.int16)
+        qf = emu.f32(q.astype(np.float32) / np.float32(32767))
+        o16 = np.zeros((B, P.hop), np.int16)
+        of = np.zeros((B, P.hop), np.float32)
+        lib.check(lib.dn_pipe_stream_push(pipe, emu.ptr(np.ascontiguousarray(q)), 1, emu.ptr(o16), 1, None, 5, 0, 32, 0.99, None))
+        lib.check(lib.dn_pipe_stream_push(pipe_f, emu.ptr(qf), 0, emu.ptr(of), 0, None, 5, 0, 32, 0.99, None))
+        assert np.array_equal(o16, (np.clip(of, -1, 1) * 32767).astype(np.int16))
+    lib.dn_pipe_destroy(pipe)
+    lib.dn_pipe_destroy(pipe_f)
+    lib.dn_model_destroy(m)

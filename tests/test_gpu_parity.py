@@ -271,3 +271,47 @@ def test_streaming_matches_oracle_golden(dev):
     assert np.sqrt(np.mean((st.ola.cpu().numpy() - g["ola"]) ** 2)) <= TOL_WAVE_RMS
     assert np.abs(st.hx.cpu().numpy() - g["hx"]).max() <= 5e-4    # hx after 30 chained steps fed by the fp32 DSP front end
     assert st.push(torch.zeros(4, 0, device=dev)).shape == (4, 0)  # empty push: nothing emitted
+
+
+def test_pipelined_stream_matches_oracle_golden_with_one_hop_delay(dev):
+    """BASELINE config 5 path: state owned by the native pipe, one launch per hop (dn_pipe_stream_*)."""
+    from audio_denoising_amd.pipeline import Denoiser, PipelinedStream
+    from oracle import pipeline_ref
+    p = pipeline_ref.PARAMS_S
+    g = load_golden("stream_S.npz")
+    dn = Denoiser(_model(dev, 5), p.sample_rate, p.n_fft, p.hop, p.n_mels)
+    ps = PipelinedStream(dn, 4)
+    sig = torch.from_numpy(g["signal"]).to(dev)
+    inits = [torch.from_numpy(a).to(dev) for a in g["init_angles"]]
+    n_frames = len(inits)
+    outs = []
+    for i in range(n_frames + 1):
+        outs.append(ps.push(sig[:, i * p.hop:(i + 1) * p.hop].contiguous(), init_angles=inits[i - 1] if i >= 1 else None))
+    outs.append(ps.flush())
+    torch.cuda.synchronize()
+    assert float(outs[0].abs().max()) == 0.0 and float(outs[1].abs().max()) == 0.0
+    y = torch.cat(outs[2:], 1).cpu().numpy()
+    assert y.shape == g["out"].shape
+    assert np.sqrt(np.mean((y - g["out"]) ** 2)) <= TOL_WAVE_RMS
+    ring, ola, hx = ps.state()
+    assert np.sqrt(np.mean((ola.cpu().numpy() - g["ola"]) ** 2)) <= TOL_WAVE_RMS
+    assert np.abs(hx.cpu().numpy() - g["hx"]).max() <= 5e-4
+    assert torch.equal(ring.cpu(), torch.from_numpy(g["signal"])[:, -p.n_fft:])
+    # checkpoint / resume of live streams: a second pipe restored from the snapshot continues identically
+    ps2 = PipelinedStream(dn, 4)
+    ps2.load_state(ring, ola, hx)
+    nxt = (0.05 * torch.randn(4, p.hop, generator=torch.Generator().manual_seed(8))).to(dev)
+    ps.seed, ps2.seed, ps2.pushes = 100, 100, ps.pushes
+    a1, b1 = ps.push(nxt), ps2.push(nxt)
+    a2, b2 = ps.flush(), ps2.flush()
+    assert torch.equal(a2, b2) and float(b1.abs().max()) == 0.0      # ps had nothing pending either: both emit ola[:hop] at flush
+    # int16 PCM in / out (app3.py:168-172, 244-245)
+    ps16 = PipelinedStream(dn, 4, seed=3)
+    psf = PipelinedStream(dn, 4, seed=3)
+    for i in range(4):
+        q = torch.clamp(torch.round(sig[:, i * p.hop:(i + 1) * p.hop] * 3.0 * 32767), -32768, 32767).to(torch.int16).contiguous()
+        o16 = ps16.push(q)
+        # numpy's true division, as app3.py:172 (torch's GPU `tensor / python_scalar` multiplies by the reciprocal instead)
+        of = psf.push(torch.from_numpy(q.cpu().numpy().astype(np.float32) / np.float32(32767)).to(dev))
+        assert o16.dtype == torch.int16
+        assert torch.equal(o16, (torch.clamp(of, -1, 1) * 32767).to(torch.int16))
