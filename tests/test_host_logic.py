@@ -71,6 +71,13 @@ def test_module_mirrors_reference_interface():
         GRUUNet2(num_compressed_bins=4, **{**CFG, "in_size": 2})  # gruunet2.py:257
 
 
+def test_sibling_gruunet_is_the_same_model_under_another_name():
+    from gruunet import GRUUNet            # server.py:33
+    from gruunet2 import GRUUNet2
+    a, b = GRUUNet(num_compressed_bins=4, **CFG), GRUUNet2(num_compressed_bins=4, **CFG)
+    assert isinstance(a, GRUUNet2) and list(a.state_dict().keys()) == list(b.state_dict().keys())
+
+
 def test_checkpoint_blob_round_trips_through_load_state_dict():
     from gruunet2 import GRUUNet2
     from oracle import model_ref
