@@ -343,9 +343,9 @@ int dn_cell_forward(const dn_model* m, const float* x, const float* hx_in, float
 
 int dn_dsp_create(const dn_dsp_cfg* cfg, const float* fb_in, const float* pinv_in, const float* window_in, dn_dsp** out) {
     if (!cfg || !out) return fail(DN_ERR_INVALID, "dn_dsp_create: null argument");
-    if (cfg->n_fft != dn::kNfft || cfg->hop != cfg->n_fft / 2)
-        return fail(DN_ERR_UNSUPPORTED, "kernels are built for n_fft = 1024, hop = 512 (got n_fft " + std::to_string(cfg->n_fft) +
-                                            ", hop " + std::to_string(cfg->hop) + ")");
+    if ((cfg->n_fft != 1024 && cfg->n_fft != 1536) || cfg->hop != cfg->n_fft / 2)
+        return fail(DN_ERR_UNSUPPORTED, "kernels are built for n_fft 1024 or 1536 with hop = n_fft/2 (got n_fft " +
+                                            std::to_string(cfg->n_fft) + ", hop " + std::to_string(cfg->hop) + ")");
     const int N = cfg->n_fft, K = N / 2 + 1, M = cfg->n_mels;
     if (M < 0 || M > 128) return fail(DN_ERR_UNSUPPORTED, "n_mels must be in 0..128");
     if (M > 0 && cfg->sample_rate <= 0) return fail(DN_ERR_INVALID, "sample_rate must be positive");
@@ -357,19 +357,20 @@ int dn_dsp_create(const dn_dsp_cfg* cfg, const float* fb_in, const float* pinv_i
     for (int n = 0; n < N; ++n) d->window[n] = window_in ? window_in[n] : (float)(0.5 - 0.5 * cos(2.0 * PI * n / N));
     std::vector<float> inv_env(N);
     for (int i = 0; i < N; ++i) {
-        const float a = d->window[i], b = d->window[(i + N / 2) & (N - 1)];
+        const float a = d->window[i], b = d->window[(i + N / 2) % N];
         const float env = a * a + b * b;
         if (!(env > 1e-11f)) { delete d; return fail(DN_ERR_INVALID, "window overlap-add envelope is ~0 (torch.istft would raise)"); }
         inv_env[i] = (float)(1.0 / (double)env);
     }
-    std::vector<float> tw512(2 * 512), tw1024(2 * 513);
-    for (int k = 0; k < 512; ++k) { tw512[2 * k] = (float)cos(2.0 * PI * k / 512); tw512[2 * k + 1] = (float)-sin(2.0 * PI * k / 512); }
-    for (int k = 0; k <= 512; ++k) { tw1024[2 * k] = (float)cos(2.0 * PI * k / 1024); tw1024[2 * k + 1] = (float)-sin(2.0 * PI * k / 1024); }
+    const int NC = N / 2;
+    std::vector<float> tw512(2 * NC), tw1024(2 * (NC / 2 + 1));     // exp(-2 pi i k / NC), exp(-2 pi i k / n_fft)
+    for (int k = 0; k < NC; ++k) { tw512[2 * k] = (float)cos(2.0 * PI * k / NC); tw512[2 * k + 1] = (float)-sin(2.0 * PI * k / NC); }
+    for (int k = 0; k <= NC / 2; ++k) { tw1024[2 * k] = (float)cos(2.0 * PI * k / N); tw1024[2 * k + 1] = (float)-sin(2.0 * PI * k / N); }
     size_t o_tw512 = d->arena.add(tw512.data(), tw512.size() * 4), o_tw1024 = d->arena.add(tw1024.data(), tw1024.size() * 4);
     size_t o_win = d->arena.add(d->window.data(), N * 4), o_env = d->arena.add(inv_env.data(), N * 4);
     size_t o_ms = 0, o_ml = 0, o_mw = 0, o_pinv = 0;
     int maxlen = 0;
-    const int pstride = (K + 7) & ~7;
+    const int pstride = ((K + 191) / 192) * 192;      // the contraction kernels stream rows in 192-bin rounds
     if (M > 0) {
         d->fb.resize((size_t)K * M);
         if (fb_in) memcpy(d->fb.data(), fb_in, d->fb.size() * 4);
@@ -427,8 +428,9 @@ int dn_dsp_create(const dn_dsp_cfg* cfg, const float* fb_in, const float* pinv_i
     hipError_t e = d->arena.upload();
     if (e != hipSuccess) { d->arena.release(); delete d; return fail(DN_ERR_HIP, std::string("plan upload: ") + hipGetErrorString(e)); }
     dn::DspDev& v = d->view;
-    v.tw512 = d->arena.ptr<float2>(o_tw512);
-    v.tw1024 = d->arena.ptr<float2>(o_tw1024);
+    v.n_fft = N;
+    v.twc = d->arena.ptr<float2>(o_tw512);
+    v.twr = d->arena.ptr<float2>(o_tw1024);
     v.window = d->arena.ptr<float>(o_win);
     v.inv_env = d->arena.ptr<float>(o_env);
     v.n_mels = M;
@@ -574,7 +576,8 @@ int dn_stream_step(const dn_model* m, const dn_dsp* d, const float* hop_in, floa
     if (B < 0) return fail(DN_ERR_INVALID, "dn_stream_step: negative batch");
     if (B == 0) return DN_OK;
     hipStream_t st = as_stream(stream);
-    dn::launch_stream_shift(hop_in, ring, B, st);
+    if (!d) return fail(DN_ERR_INVALID, "dn_stream_step: null plan");
+    dn::launch_stream_shift(d->cfg.n_fft, hop_in, ring, B, st);
     int rc = check_launch("stream_shift_kernel");
     if (rc != DN_OK) return rc;
     // the denoised frame lands at the head of the workspace tail (after the process_frame scratch)
@@ -582,7 +585,7 @@ int dn_stream_step(const dn_model* m, const dn_dsp* d, const float* hop_in, floa
     float* y = reinterpret_cast<float*>(static_cast<char*>(workspace) + frame_scratch_bytes(d, B));
     rc = dn_process_frame(m, d, ring, hx, y, nullptr, init_angles, seed, stream_id0, n_iter, momentum, workspace, B, stream);
     if (rc != DN_OK) return rc;
-    dn::launch_stream_ola(y, ola, hop_out, B, st);
+    dn::launch_stream_ola(d->cfg.n_fft, y, ola, hop_out, B, st);
     return check_launch("stream_ola_kernel");
 }
 

@@ -33,17 +33,20 @@ __device__ __forceinline__ v2f rand_angle(uint64_t seed, uint64_t sid, int col, 
 //                   computes P8-P10 in place -- leaky_relu(x - diff, 0.2), expm1, clamp, the pinv(fb^T)
 //                   contraction and relu (app3.py:203-211) -- into LDS, so the linear magnitudes never
 //                   touch HBM and the separate inverse-mel launch disappears from the fused hop.
-constexpr int kGlSmem = 8 * 3 * kFftTile + 4 * 2 * 2 * kNR;      // 30,208 B
+template <int NFFT> constexpr int gl_smem() { return 8 * 3 * Geo<NFFT>::kTile + 4 * 2 * 2 * NFFT; }    // 30,208 B at 1024
 
-// One workgroup (192 threads = 3 wavefronts = 3 columns) runs all iterations for stream `b`.  `smem`: kGlSmem bytes.
+// One workgroup (192 threads = 3 wavefronts = 3 columns) runs all iterations for stream `b`.  `smem`: gl_smem<NFFT>() bytes.
 // STREAM = true: instead of storing the frame, fold it into the stream's overlap-add line (P12, app3.py:219-224):
 //   hop_out <- ola[:hop] (float, or clipped int16 as app3.py:244-245); ola <- concat(ola[hop:], 0) + frame.
-template <bool FROM_MEL, bool STREAM = false>
+template <int NFFT, bool FROM_MEL, bool STREAM = false>
 __device__ __forceinline__ void gl_body(char* smem, const DspDev& d, const float* __restrict__ mag,
                                         const float* __restrict__ diff, const v2f* __restrict__ init, uint64_t seed,
                                         uint64_t sid0, const float* __restrict__ scale, float* __restrict__ wave,
                                         int n_iter, float mom, size_t b, int tid, float* ola = nullptr,
                                         void* hop_out = nullptr, int out_s16 = 0) {
+    using G = Geo<NFFT>;
+    constexpr int kNR = G::kNR, kNC = G::kNC, kHop = G::kHop, kBins = G::kBins, kNV = G::kNV, kNP = G::kNP, kFftTile = G::kTile;
+    constexpr int kBinPad = (kBins + 7) & ~7;                  // row stride of the LDS magnitude scratch
     v2f (*tile)[kFftTile] = reinterpret_cast<v2f (*)[kFftTile]>(smem);
     // [ping-pong][0: centre column, 1: halves of columns 0 and 2][n]
     float (*ybuf)[2][kNR] = reinterpret_cast<float (*)[2][kNR]>(smem + 8 * 3 * kFftTile);
@@ -53,8 +56,9 @@ __device__ __forceinline__ void gl_body(char* smem, const DspDev& d, const float
     v2f* mytile = tile[w];
 
     // prologue scratch aliases the overlap-add lines (used only before the first iteration)
-    float* mm = &ybuf[0][0][0];           // [3][128]  mel magnitudes
-    float* lmag = &ybuf[1][0][0];         // [3][520]  linear magnitudes
+    float* mm = &ybuf[0][0][0];           // [3][128]      mel magnitudes
+    float* lmag = &ybuf[1][0][0];         // [3][kBinPad]  linear magnitudes
+    static_assert(3 * kBinPad <= 2 * kNR && 3 * 128 <= 2 * kNR, "prologue scratch fits one ping-pong half");
     if (FROM_MEL) {
         const int M = d.n_mels;
         for (int i = tid; i < 3 * M; i += kGlThreads) {
@@ -64,75 +68,77 @@ __device__ __forceinline__ void gl_body(char* smem, const DspDev& d, const float
             mm[c * 128 + m] = fmaxf(expm1f(v), 0.0f);  // app3.py:207-208
         }
         __syncthreads();
-        // thread <-> bins tid, tid+192, tid+384: each pinv element is loaded once and used for all 3 columns
-        float acc[3][3];
+        // thread <-> bins tid, tid+192, ..: each pinv element is loaded once and used for all 3 columns (pinv_t rows are
+        // zero padded to pinv_stride >= kRounds*192, so the tail loads are in bounds)
+        constexpr int kRounds = (kBins + kGlThreads - 1) / kGlThreads;
+        float acc[kRounds][3];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) acc[r][0] = acc[r][1] = acc[r][2] = 0.0f;
+        for (int r = 0; r < kRounds; ++r) acc[r][0] = acc[r][1] = acc[r][2] = 0.0f;
         const float* p = d.pinv_t + tid;
-        const bool third = tid + 384 < kBins;
-#pragma unroll 8
+#pragma unroll 4
         for (int m = 0; m < M; ++m) {
             const float* pm = p + (size_t)m * d.pinv_stride;
-            const float p0 = pm[0], p1 = pm[192], p2 = third ? pm[384] : 0.0f;
             const float m0 = mm[m], m1 = mm[128 + m], m2 = mm[256 + m];
-            acc[0][0] = fmaf(p0, m0, acc[0][0]); acc[0][1] = fmaf(p0, m1, acc[0][1]); acc[0][2] = fmaf(p0, m2, acc[0][2]);
-            acc[1][0] = fmaf(p1, m0, acc[1][0]); acc[1][1] = fmaf(p1, m1, acc[1][1]); acc[1][2] = fmaf(p1, m2, acc[1][2]);
-            acc[2][0] = fmaf(p2, m0, acc[2][0]); acc[2][1] = fmaf(p2, m1, acc[2][1]); acc[2][2] = fmaf(p2, m2, acc[2][2]);
+#pragma unroll
+            for (int r = 0; r < kRounds; ++r) {
+                const float pv = pm[kGlThreads * r];
+                acc[r][0] = fmaf(pv, m0, acc[r][0]); acc[r][1] = fmaf(pv, m1, acc[r][1]); acc[r][2] = fmaf(pv, m2, acc[r][2]);
+            }
         }
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const int k = tid + 192 * r;
+        for (int r = 0; r < kRounds; ++r) {
+            const int k = tid + kGlThreads * r;
             if (k < kBins) {
 #pragma unroll
-                for (int c = 0; c < 3; ++c) lmag[c * 520 + k] = fmaxf(acc[r][c], 0.0f);    // relu + clamp, app3.py:210-211
+                for (int c = 0; c < 3; ++c) lmag[c * kBinPad + k] = fmaxf(acc[r][c], 0.0f);    // relu + clamp, app3.py:210-211
             }
         }
         __syncthreads();
     }
 
-    FftTwiddles tw;
-    load_twiddles(tw, d.tw512, lane);
+    typename G::Fft::Tw tw;
+    G::Fft::load(tw, reinterpret_cast<const v2f*>(d.twc), lane);
 
-    // lane constants: bin twiddles of the owned pairs, synthesis window / 512, analysis window * 1/envelope
-    // and the source sample indices of this column in the rebuilt signal s[0..1024):
-    //   column 0: n < 512 -> s[512-n] (reflection), else s[n-512]
+    // lane constants: bin twiddles of the owned pairs, synthesis window / NC, analysis window * 1/envelope
+    // and the source sample indices of this column in the rebuilt signal s[0..n_fft)  (H = hop = n_fft/2):
+    //   column 0: n < H -> s[H-n] (reflection), else s[n-H]
     //   column 1: s[n]
-    //   column 2: n < 512 -> s[n+512], else s[1534-n] (reflection)
-    v2f wkh[4], wsyn[8], cw[8];
-    int src0[8], src1[8];
+    //   column 2: n < H -> s[n+H], else s[3H-2-n] (reflection)
+    v2f wkh[kNP], wsyn[kNV], cw[kNV];
+    int src0[kNV], src1[kNV];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) wkh[t] = cscale(reinterpret_cast<const v2f*>(d.tw1024)[lane + 64 * t], 0.5f);
+    for (int t = 0; t < kNP; ++t) wkh[t] = cscale(reinterpret_cast<const v2f*>(d.twr)[lane + 64 * t], 0.5f);
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
+    for (int t = 0; t < kNV; ++t) {
         const int m = lane + 64 * t;
         const v2f ww = reinterpret_cast<const v2f*>(d.window)[m];
-        wsyn[t] = cscale(ww, 1.0f / 512.0f);
+        wsyn[t] = cscale(ww, 1.0f / (float)kNC);
         const int n0 = 2 * m, n1 = n0 + 1;
         int i0, i1;
         if (w == 1) { i0 = n0; i1 = n1; }
-        else if (w == 0) { i0 = n0 < 512 ? 512 - n0 : n0 - 512; i1 = n1 < 512 ? 512 - n1 : n1 - 512; }
-        else { i0 = n0 < 512 ? n0 + 512 : 1534 - n0; i1 = n1 < 512 ? n1 + 512 : 1534 - n1; }
+        else if (w == 0) { i0 = n0 < kHop ? kHop - n0 : n0 - kHop; i1 = n1 < kHop ? kHop - n1 : n1 - kHop; }
+        else { i0 = n0 < kHop ? n0 + kHop : 3 * kHop - 2 - n0; i1 = n1 < kHop ? n1 + kHop : 3 * kHop - 2 - n1; }
         src0[t] = i0; src1[t] = i1;
         cw[t] = mk2(ww[0] * d.inv_env[i0], ww[1] * d.inv_env[i1]);
     }
 
-    // per-lane state: the 4 bin pairs (k, 512-k), k = lane + 64 t, plus bin 256 (meaningful in lane 0)
-    float mlo[4], mhi[4], mmid;
-    v2f alo[4], ahi[4], amid, plo[4], phi[4], pmid;
+    // per-lane state: the NP bin pairs (k, NC-k), k = lane + 64 t, plus bin NC/2 (meaningful in lane 0)
+    float mlo[kNP], mhi[kNP], mmid;
+    v2f alo[kNP], ahi[kNP], amid, plo[kNP], phi[kNP], pmid;
     {
         const size_t row = (b * 3 + w) * kBins;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int k = lane + 64 * t, kh = 512 - k;
-            mlo[t] = FROM_MEL ? lmag[w * 520 + k] : (mag != nullptr ? mag[row + k] : 1.0f);
-            mhi[t] = FROM_MEL ? lmag[w * 520 + kh] : (mag != nullptr ? mag[row + kh] : 1.0f);
+        for (int t = 0; t < kNP; ++t) {
+            const int k = lane + 64 * t, kh = kNC - k;
+            mlo[t] = FROM_MEL ? lmag[w * kBinPad + k] : (mag != nullptr ? mag[row + k] : 1.0f);
+            mhi[t] = FROM_MEL ? lmag[w * kBinPad + kh] : (mag != nullptr ? mag[row + kh] : 1.0f);
             alo[t] = init != nullptr ? init[row + k] : rand_angle(seed, sid0 + b, w, k);
             ahi[t] = init != nullptr ? init[row + kh] : rand_angle(seed, sid0 + b, w, kh);
             plo[t] = mk2(0.0f, 0.0f);
             phi[t] = mk2(0.0f, 0.0f);
         }
-        mmid = FROM_MEL ? lmag[w * 520 + 256] : (mag != nullptr ? mag[row + 256] : 1.0f);
-        amid = init != nullptr ? init[row + 256] : rand_angle(seed, sid0 + b, w, 256);
+        mmid = FROM_MEL ? lmag[w * kBinPad + kNC / 2] : (mag != nullptr ? mag[row + kNC / 2] : 1.0f);
+        amid = init != nullptr ? init[row + kNC / 2] : rand_angle(seed, sid0 + b, w, kNC / 2);
         pmid = mk2(0.0f, 0.0f);
     }
 
@@ -146,26 +152,26 @@ __device__ __forceinline__ void gl_body(char* smem, const DspDev& d, const float
 
     if (FROM_MEL) __syncthreads();        // the prologue scratch becomes the overlap-add lines
 
-    v2f v[8], xlo[4], xhi[4], xmid;
+    v2f v[kNV], xlo[kNP], xhi[kNP], xmid;
     for (int it = 0;; ++it) {
         // ---- istft of angles * magnitude: Hermitian merge, inverse FFT, synthesis window, overlap-add lines
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < kNP; ++t) {
             xlo[t] = alo[t] * mlo[t];
             xhi[t] = ahi[t] * mhi[t];
         }
         xmid = amid * mmid;
-        irfft_merge_pairs(xlo, xhi, xmid, wkh, lane, v);
-        fft512<true>(v, tw, mytile, lane);
+        irfft_merge_pairs<kNV>(xlo, xhi, xmid, wkh, lane, v);
+        G::Fft::template run<true>(v, tw, mytile, lane);
         float* y1 = ybuf[it & 1][0];
         float* yo = ybuf[it & 1][1];
         {
-            // column 1 -> y1[n]; column 0 keeps its second half -> yo[n-512]; column 2 its first half -> yo[n+512]
+            // column 1 -> y1[n]; column 0 keeps its second half -> yo[n-H]; column 2 its first half -> yo[n+H]
             // (the other halves fall outside the samples the istft trim keeps and are simply not stored)
-            float* ydst = w == 1 ? y1 : (w == 0 ? yo - 512 : yo + 512);
-            const int t_lo = w == 0 ? 4 : 0, t_hi = w == 2 ? 4 : 8;
+            float* ydst = w == 1 ? y1 : (w == 0 ? yo - kHop : yo + kHop);
+            const int t_lo = w == 0 ? kNP : 0, t_hi = w == 2 ? kNP : kNV;
 #pragma unroll
-            for (int t = 0; t < 8; ++t)
+            for (int t = 0; t < kNV; ++t)
                 if (t >= t_lo && t < t_hi) *reinterpret_cast<v2f*>(ydst + 2 * (lane + 64 * t)) = v[t] * wsyn[t];
         }
         __syncthreads();
@@ -206,13 +212,13 @@ __device__ __forceinline__ void gl_body(char* smem, const DspDev& d, const float
         }
         // ---- stft of the rebuilt signal (centre, reflect): this wave's column, analysis window
 #pragma unroll
-        for (int t = 0; t < 8; ++t)
+        for (int t = 0; t < kNV; ++t)
             v[t] = mk2(y1[src0[t]] + yo[src0[t]], y1[src1[t]] + yo[src1[t]]) * cw[t];
-        fft512<false>(v, tw, mytile, lane);
-        rfft_split_pairs(v, wkh, lane, xlo, xhi, xmid);
+        G::Fft::template run<false>(v, tw, mytile, lane);
+        rfft_split_pairs<kNV>(v, wkh, lane, xlo, xhi, xmid);
         // ---- phase update with momentum
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < kNP; ++t) {
             update(xlo[t], plo[t], alo[t]);
             update(xhi[t], phi[t], ahi[t]);
         }

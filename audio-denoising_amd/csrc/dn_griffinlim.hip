@@ -18,29 +18,35 @@
 
 namespace dn {
 
-template <bool FROM_MEL>
+template <int NFFT, bool FROM_MEL>
 __global__ __launch_bounds__(kGlThreads) void griffinlim_kernel(DspDev d, const float* __restrict__ mag,
                                                                 const float* __restrict__ diff,
                                                                 const v2f* __restrict__ init, uint64_t seed,
                                                                 uint64_t sid0, const float* __restrict__ scale,
                                                                 float* __restrict__ wave, int n_iter, float mom) {
-    __shared__ __attribute__((aligned(16))) char smem[kGlSmem];
-    gl_body<FROM_MEL>(smem, d, mag, diff, init, seed, sid0, scale, wave, n_iter, mom, blockIdx.x, threadIdx.x);
+    __shared__ __attribute__((aligned(16))) char smem[gl_smem<NFFT>()];
+    gl_body<NFFT, FROM_MEL>(smem, d, mag, diff, init, seed, sid0, scale, wave, n_iter, mom, blockIdx.x, threadIdx.x);
 }
 
 void launch_griffinlim(const DspDev& d, const float* mag, const float* init, uint64_t seed, uint64_t sid0,
                        const float* scale, float* wave, int B, int n_iter, float momentum, hipStream_t st) {
     const float mom = momentum / (1.0f + momentum);
-    hipLaunchKernelGGL((griffinlim_kernel<false>), dim3(B), dim3(kGlThreads), 0, st, d, mag, (const float*)nullptr,
-                       reinterpret_cast<const v2f*>(init), seed, sid0, scale, wave, n_iter, mom);
+    const v2f* ia = reinterpret_cast<const v2f*>(init);
+    if (d.n_fft == 1536)
+        hipLaunchKernelGGL((griffinlim_kernel<1536, false>), dim3(B), dim3(kGlThreads), 0, st, d, mag, (const float*)nullptr, ia, seed, sid0, scale, wave, n_iter, mom);
+    else
+        hipLaunchKernelGGL((griffinlim_kernel<1024, false>), dim3(B), dim3(kGlThreads), 0, st, d, mag, (const float*)nullptr, ia, seed, sid0, scale, wave, n_iter, mom);
 }
 
 // P8..P12 in one launch: residual -> mel magnitude -> inverse mel -> Griffin-Lim -> * peak.
 void launch_synthesis(const DspDev& d, const float* x, const float* diff, const float* init, uint64_t seed, uint64_t sid0,
                       const float* scale, float* wave, int B, int n_iter, float momentum, hipStream_t st) {
     const float mom = momentum / (1.0f + momentum);
-    hipLaunchKernelGGL((griffinlim_kernel<true>), dim3(B), dim3(kGlThreads), 0, st, d, x, diff,
-                       reinterpret_cast<const v2f*>(init), seed, sid0, scale, wave, n_iter, mom);
+    const v2f* ia = reinterpret_cast<const v2f*>(init);
+    if (d.n_fft == 1536)
+        hipLaunchKernelGGL((griffinlim_kernel<1536, true>), dim3(B), dim3(kGlThreads), 0, st, d, x, diff, ia, seed, sid0, scale, wave, n_iter, mom);
+    else
+        hipLaunchKernelGGL((griffinlim_kernel<1024, true>), dim3(B), dim3(kGlThreads), 0, st, d, x, diff, ia, seed, sid0, scale, wave, n_iter, mom);
 }
 
 }  // namespace dn

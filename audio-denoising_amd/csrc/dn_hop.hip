@@ -20,26 +20,29 @@
 namespace dn {
 
 constexpr int kHopThreads = 192;
-constexpr int kHopSmem = kCellSmem > kGlSmem ? (kCellSmem > kStftSmem ? kCellSmem : kStftSmem)
-                                             : (kGlSmem > kStftSmem ? kGlSmem : kStftSmem);
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+template <int NFFT> constexpr int hop_smem() { return cmax(cmax(kCellSmem, gl_smem<NFFT>()), cmax(stft_smem<NFFT>(), kInvSmem)); }
 static_assert(kHopThreads == kGlThreads && kHopThreads == kStftThreads && kHopThreads == kInvThreads, "one block size for all bodies");
 
+template <int NFFT>
 __global__ __launch_bounds__(kHopThreads) void hop_kernel(DspDev d, CellDev cd, HopArgs a) {
-    __shared__ __attribute__((aligned(16))) char smem[kHopSmem];
+    constexpr int kNR = NFFT;
+    __shared__ __attribute__((aligned(16))) char smem[hop_smem<NFFT>()];
     const int tid = threadIdx.x;
     if ((int)blockIdx.x < a.back_B) {
         if (a.ola == nullptr)
-            gl_body<false, false>(smem, d, a.gl_lin, nullptr, reinterpret_cast<const v2f*>(a.gl_init), a.gl_seed, a.gl_sid0,
-                                  a.gl_peak, a.gl_out, a.n_iter, a.mom, blockIdx.x, tid);
+            gl_body<NFFT, false, false>(smem, d, a.gl_lin, nullptr, reinterpret_cast<const v2f*>(a.gl_init), a.gl_seed, a.gl_sid0,
+                                        a.gl_peak, a.gl_out, a.n_iter, a.mom, blockIdx.x, tid);
         else
-            gl_body<false, true>(smem, d, a.gl_lin, nullptr, reinterpret_cast<const v2f*>(a.gl_init), a.gl_seed, a.gl_sid0,
-                                 a.gl_peak, nullptr, a.n_iter, a.mom, blockIdx.x, tid, a.ola, a.hop_out, a.out_s16);
+            gl_body<NFFT, false, true>(smem, d, a.gl_lin, nullptr, reinterpret_cast<const v2f*>(a.gl_init), a.gl_seed, a.gl_sid0,
+                                       a.gl_peak, nullptr, a.n_iter, a.mom, blockIdx.x, tid, a.ola, a.hop_out, a.out_s16);
     } else {
         const size_t b = blockIdx.x - a.back_B;
         const float* frames = a.frames;
         if (a.ring != nullptr) {
             // ring <- concat(ring[hop:], hop_in): every thread holds its float4s before anything is overwritten
             constexpr int kLine4 = kNR / 4, kHop4 = kNR / 8;
+            static_assert(kLine4 <= 2 * kHopThreads, "two float4 per thread cover the line");
             float4* r4 = reinterpret_cast<float4*>(a.ring + b * kNR);
             float4 v[2];
 #pragma unroll
@@ -67,16 +70,17 @@ __global__ __launch_bounds__(kHopThreads) void hop_kernel(DspDev d, CellDev cd, 
             if (a.prime_only) return;
             frames = a.ring;
         }
-        stft_body<false, true>(smem, d, frames, nullptr, a.mel, a.peak, DN_PEAK_NORMALIZE | DN_PRE_WINDOW, b, tid);   // P1-P6
+        stft_body<NFFT, false, true>(smem, d, frames, nullptr, a.mel, a.peak, DN_PEAK_NORMALIZE | DN_PRE_WINDOW, b, tid);   // P1-P6
         __syncthreads();
-        cell_body<kHopThreads / 64>(smem, cd, a.mel, a.hx, a.diff, a.hx, 3, a.C, b, tid);                               // P7
+        cell_body<kHopThreads / 64>(smem, cd, a.mel, a.hx, a.diff, a.hx, 3, a.C, b, tid);                                   // P7
         __syncthreads();
-        invmel_body<true>(smem, d, a.mel, a.diff, a.lin, 3 * a.front_B, b * 3, tid);                                    // P8-P10
+        invmel_body<NFFT, true>(smem, d, a.mel, a.diff, a.lin, 3 * a.front_B, b * 3, tid);                                  // P8-P10
     }
 }
 
 void launch_hop(const DspDev& d, const CellDev& c, const HopArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(hop_kernel, dim3(a.back_B + a.front_B), dim3(kHopThreads), 0, st, d, c, a);
+    if (d.n_fft == 1536) hipLaunchKernelGGL(hop_kernel<1536>, dim3(a.back_B + a.front_B), dim3(kHopThreads), 0, st, d, c, a);
+    else hipLaunchKernelGGL(hop_kernel<1024>, dim3(a.back_B + a.front_B), dim3(kHopThreads), 0, st, d, c, a);
 }
 
 }  // namespace dn

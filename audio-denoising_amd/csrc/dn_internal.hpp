@@ -23,7 +23,6 @@ typedef const DN_CONST_AS float* cfloat_ptr;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #endif
 
-constexpr int kNfft = 1024;     // n_fft the FFT kernels are built for (hop = 512)
 constexpr int kHidden = 17;      // H
 constexpr int kGates = 51;       // 3H
 constexpr int kGauss = 6;        // G
@@ -54,7 +53,7 @@ struct HopArgs {
     float* ola; void* hop_out; int out_s16;
 };
 void launch_hop(const DspDev& d, const CellDev& c, const HopArgs& a, hipStream_t st);
-void launch_stream_shift(const float* hop_in, float* ring, int B, hipStream_t st);
-void launch_stream_ola(const float* y, float* ola, float* hop_out, int B, hipStream_t st);
+void launch_stream_shift(int n_fft, const float* hop_in, float* ring, int B, hipStream_t st);
+void launch_stream_ola(int n_fft, const float* y, float* ola, float* hop_out, int B, hipStream_t st);
 
 }  // namespace dn

@@ -13,20 +13,26 @@
 
 namespace dn {
 
-template <bool RESIDUAL>
+template <int NFFT, bool RESIDUAL>
 __global__ __launch_bounds__(kInvThreads) void invmel_kernel(DspDev d, const float* __restrict__ x,
                                                              const float* __restrict__ diff, float* __restrict__ lin,
                                                              int rows) {
     __shared__ __attribute__((aligned(16))) char smem[kInvSmem];
-    invmel_body<RESIDUAL>(smem, d, x, diff, lin, rows, (size_t)blockIdx.x * kInvRows, threadIdx.x);
+    invmel_body<NFFT, RESIDUAL>(smem, d, x, diff, lin, rows, (size_t)blockIdx.x * kInvRows, threadIdx.x);
+}
+
+template <int NFFT>
+static void launch_invmel_n(const DspDev& d, const float* x, const float* diff, float* lin, int rows, hipStream_t st) {
+    dim3 grid((rows + kInvRows - 1) / kInvRows), block(kInvThreads);
+    if (diff != nullptr)
+        hipLaunchKernelGGL((invmel_kernel<NFFT, true>), grid, block, 0, st, d, x, diff, lin, rows);
+    else
+        hipLaunchKernelGGL((invmel_kernel<NFFT, false>), grid, block, 0, st, d, x, diff, lin, rows);
 }
 
 void launch_invmel(const DspDev& d, const float* x, const float* diff, float* lin, int rows, hipStream_t st) {
-    dim3 grid((rows + kInvRows - 1) / kInvRows), block(kInvThreads);
-    if (diff != nullptr)
-        hipLaunchKernelGGL((invmel_kernel<true>), grid, block, 0, st, d, x, diff, lin, rows);
-    else
-        hipLaunchKernelGGL((invmel_kernel<false>), grid, block, 0, st, d, x, diff, lin, rows);
+    if (d.n_fft == 1536) launch_invmel_n<1536>(d, x, diff, lin, rows, st);
+    else launch_invmel_n<1024>(d, x, diff, lin, rows, st);
 }
 
 }  // namespace dn

@@ -12,10 +12,11 @@ constexpr int kMaxMels = 128;
 constexpr int kInvSmem = 4 * kInvRows * kMaxMels;
 
 // One workgroup (192 threads) handles rows r0 .. r0+2 (the three columns of one stream).  `smem`: kInvSmem bytes.
-template <bool RESIDUAL>
+template <int NFFT, bool RESIDUAL>
 __device__ __forceinline__ void invmel_body(char* smem, const DspDev& d, const float* __restrict__ x,
                                             const float* __restrict__ diff, float* __restrict__ lin, int rows,
                                             size_t r0, int tid) {
+    constexpr int kBins = Geo<NFFT>::kBins;
     float (*mm)[kMaxMels] = reinterpret_cast<float (*)[kMaxMels]>(smem);
     const int M = d.n_mels;
     for (int i = tid; i < kInvRows * M; i += kInvThreads) {
@@ -32,23 +33,24 @@ __device__ __forceinline__ void invmel_body(char* smem, const DspDev& d, const f
         mm[r][m] = v;
     }
     __syncthreads();
-    // thread <-> bins tid, tid+192, tid+384: three independent load streams, 8 rows of pinv_t in flight each
-    float acc[3][3];
+    // thread <-> bins tid, tid+192, ..: independent load streams (pinv_t rows are zero padded to a multiple of 192)
+    constexpr int kRounds = (kBins + kInvThreads - 1) / kInvThreads;
+    float acc[kRounds][3];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) acc[r][0] = acc[r][1] = acc[r][2] = 0.0f;
+    for (int r = 0; r < kRounds; ++r) acc[r][0] = acc[r][1] = acc[r][2] = 0.0f;
     const float* p = d.pinv_t + tid;
-    const bool third = tid + 2 * kInvThreads < kBins;
-#pragma unroll 8
+#pragma unroll 4
     for (int m = 0; m < M; ++m) {
         const float* pm = p + (size_t)m * d.pinv_stride;
-        const float p0 = pm[0], p1 = pm[kInvThreads], p2 = third ? pm[2 * kInvThreads] : 0.0f;
         const float m0 = mm[0][m], m1 = mm[1][m], m2 = mm[2][m];
-        acc[0][0] = fmaf(p0, m0, acc[0][0]); acc[0][1] = fmaf(p0, m1, acc[0][1]); acc[0][2] = fmaf(p0, m2, acc[0][2]);
-        acc[1][0] = fmaf(p1, m0, acc[1][0]); acc[1][1] = fmaf(p1, m1, acc[1][1]); acc[1][2] = fmaf(p1, m2, acc[1][2]);
-        acc[2][0] = fmaf(p2, m0, acc[2][0]); acc[2][1] = fmaf(p2, m1, acc[2][1]); acc[2][2] = fmaf(p2, m2, acc[2][2]);
+#pragma unroll
+        for (int r = 0; r < kRounds; ++r) {
+            const float pv = pm[kInvThreads * r];
+            acc[r][0] = fmaf(pv, m0, acc[r][0]); acc[r][1] = fmaf(pv, m1, acc[r][1]); acc[r][2] = fmaf(pv, m2, acc[r][2]);
+        }
     }
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
+    for (int r = 0; r < kRounds; ++r) {
         const int k = tid + kInvThreads * r;
         if (k < kBins) {
 #pragma unroll

@@ -7,10 +7,11 @@ namespace dn {
 
 // STFT / mel / inverse-mel / Griffin-Lim constants, all resident in HBM (L2-hot: ~0.4 MB total).
 struct DspDev {
-    const float2* tw512;    // [512]  exp(-2 pi i k/512)
-    const float2* tw1024;   // [513]  exp(-2 pi i k/1024)
-    const float* window;    // [1024] analysis == synthesis window (periodic Hann by default)
-    const float* inv_env;   // [1024] 1 / (w[i]^2 + w[(i+512)&1023]^2): istft envelope over the kept region
+    int n_fft;              // 1024 or 1536; NC = n_fft/2 is the complex FFT length, K = NC + 1 bins
+    const float2* twc;      // [NC]     exp(-2 pi i k / NC)
+    const float2* twr;      // [NC/2+1] exp(-2 pi i k / n_fft)
+    const float* window;    // [n_fft]  analysis == synthesis window (periodic Hann by default)
+    const float* inv_env;   // [n_fft]  1 / (w[i]^2 + w[(i + hop) % n_fft]^2): istft envelope over the kept region
     // banded mel filterbank: filter m covers bins [mel_start[m], mel_start[m]+mel_len[m])
     const int* mel_start;   // [M]
     const int* mel_len;     // [M]

@@ -9,20 +9,21 @@
 
 namespace dn {
 
-template <bool WRITE_SPEC, bool WRITE_MEL>
+template <int NFFT, bool WRITE_SPEC, bool WRITE_MEL>
 __global__ __launch_bounds__(kStftThreads) void stft_kernel(DspDev d, const float* __restrict__ frames,
                                                             float2* __restrict__ spec, float* __restrict__ mel,
                                                             float* __restrict__ peak_out, uint32_t flags) {
-    __shared__ __attribute__((aligned(16))) char smem[kStftSmem];
-    stft_body<WRITE_SPEC, WRITE_MEL>(smem, d, frames, spec, mel, peak_out, flags, blockIdx.x, threadIdx.x);
+    __shared__ __attribute__((aligned(16))) char smem[stft_smem<NFFT>()];
+    stft_body<NFFT, WRITE_SPEC, WRITE_MEL>(smem, d, frames, spec, mel, peak_out, flags, blockIdx.x, threadIdx.x);
 }
 
 // MelScale alone (app3.py:193 without the log): one wavefront per (b,t) row.
 __global__ __launch_bounds__(64) void mel_kernel(DspDev d, const float* __restrict__ mag, float* __restrict__ mel) {
-    __shared__ float row[kBins + 7];
+    __shared__ float row[Geo<1536>::kBins + 7];
     const int lane = threadIdx.x;
     const size_t r = blockIdx.x;
-    for (int k = lane; k < kBins; k += 64) row[k] = mag[r * kBins + k];
+    const int bins = d.n_fft / 2 + 1;
+    for (int k = lane; k < bins; k += 64) row[k] = mag[r * bins + k];
     wave_sync();
     for (int m = lane; m < d.n_mels; m += 64) {
         const int s = d.mel_start[m], len = d.mel_len[m];
@@ -32,15 +33,23 @@ __global__ __launch_bounds__(64) void mel_kernel(DspDev d, const float* __restri
     }
 }
 
+template <int NFFT>
+static void launch_stft_n(const DspDev& d, const float* frames, float* spec, float* mel, float* peak, int B, uint32_t flags,
+                          hipStream_t st) {
+    dim3 grid(B), block(kStftThreads);
+    float2* sp = reinterpret_cast<float2*>(spec);
+    if (spec != nullptr && mel != nullptr)
+        hipLaunchKernelGGL((stft_kernel<NFFT, true, true>), grid, block, 0, st, d, frames, sp, mel, peak, flags);
+    else if (spec != nullptr)
+        hipLaunchKernelGGL((stft_kernel<NFFT, true, false>), grid, block, 0, st, d, frames, sp, mel, peak, flags);
+    else
+        hipLaunchKernelGGL((stft_kernel<NFFT, false, true>), grid, block, 0, st, d, frames, sp, mel, peak, flags);
+}
+
 void launch_stft(const DspDev& d, const float* frames, float* spec, float* mel, float* peak, int B, uint32_t flags,
                  hipStream_t st) {
-    dim3 grid(B), block(kStftThreads);
-    if (spec != nullptr && mel != nullptr)
-        hipLaunchKernelGGL((stft_kernel<true, true>), grid, block, 0, st, d, frames, reinterpret_cast<float2*>(spec), mel, peak, flags);
-    else if (spec != nullptr)
-        hipLaunchKernelGGL((stft_kernel<true, false>), grid, block, 0, st, d, frames, reinterpret_cast<float2*>(spec), mel, peak, flags);
-    else
-        hipLaunchKernelGGL((stft_kernel<false, true>), grid, block, 0, st, d, frames, reinterpret_cast<float2*>(spec), mel, peak, flags);
+    if (d.n_fft == 1536) launch_stft_n<1536>(d, frames, spec, mel, peak, B, flags, st);
+    else launch_stft_n<1024>(d, frames, spec, mel, peak, B, flags, st);
 }
 
 void launch_mel(const DspDev& d, const float* mag, float* mel, int rows, hipStream_t st) {

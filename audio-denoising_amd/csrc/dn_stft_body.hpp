@@ -13,13 +13,15 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-constexpr int kStftSmem = 4 * kNR + 8 * 3 * kFftTile + 4 * 3 * (kBins + 7) + 16;    // 24,176 B
+template <int NFFT> constexpr int stft_smem() { return 4 * NFFT + 8 * 3 * Geo<NFFT>::kTile + 4 * 3 * (Geo<NFFT>::kBins + 7) + 16; }
 
-// One workgroup (192 threads = 3 wavefronts = 3 STFT columns) processes frame `b`.  `smem`: kStftSmem bytes of LDS.
-template <bool WRITE_SPEC, bool WRITE_MEL>
+// One workgroup (192 threads = 3 wavefronts = 3 STFT columns) processes frame `b`.  `smem`: stft_smem<NFFT>() bytes of LDS.
+template <int NFFT, bool WRITE_SPEC, bool WRITE_MEL>
 __device__ __forceinline__ void stft_body(char* smem, const DspDev& d, const float* __restrict__ frames,
                                           float2* __restrict__ spec, float* __restrict__ mel,
                                           float* __restrict__ peak_out, uint32_t flags, size_t b, int tid) {
+    using G = Geo<NFFT>;
+    constexpr int kNR = G::kNR, kHop = G::kHop, kBins = G::kBins, kNV = G::kNV, kNP = G::kNP, kFftTile = G::kTile;
     float* xs = reinterpret_cast<float*>(smem);
     v2f (*tile)[kFftTile] = reinterpret_cast<v2f (*)[kFftTile]>(smem + 4 * kNR);
     float (*magbuf)[kBins + 7] = reinterpret_cast<float (*)[kBins + 7]>(smem + 4 * kNR + 8 * 3 * kFftTile);
@@ -32,6 +34,7 @@ __device__ __forceinline__ void stft_body(char* smem, const DspDev& d, const flo
     const float4* f4 = reinterpret_cast<const float4*>(frames + b * kNR);
     float4 q0 = f4[tid];
     float4 q1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    static_assert(kNR / 4 <= 2 * kStftThreads, "two float4 per thread cover the frame");
     const bool two = tid < (kNR / 4 - kStftThreads);
     if (two) q1 = f4[tid + kStftThreads];
     float mx = fmaxf(fmaxf(fabsf(q0.x), fabsf(q0.y)), fmaxf(fabsf(q0.z), fabsf(q0.w)));
@@ -58,44 +61,44 @@ __device__ __forceinline__ void stft_body(char* smem, const DspDev& d, const flo
     if (two) prep(q1, tid + kStftThreads);
     __syncthreads();
 
-    // ---- P4: column w of the centred STFT: padded position p = 512 w + n, source i = p - 512 reflected
-    FftTwiddles tw;
-    load_twiddles(tw, d.tw512, lane);
-    v2f wkh[4], v[8];
+    // ---- P4: column w of the centred STFT: padded position p = hop w + n, source i = p - hop reflected
+    typename G::Fft::Tw tw;
+    G::Fft::load(tw, reinterpret_cast<const v2f*>(d.twc), lane);
+    v2f wkh[kNP], v[kNV];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) wkh[t] = cscale(reinterpret_cast<const v2f*>(d.tw1024)[lane + 64 * t], 0.5f);
+    for (int t = 0; t < kNP; ++t) wkh[t] = cscale(reinterpret_cast<const v2f*>(d.twr)[lane + 64 * t], 0.5f);
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
+    for (int t = 0; t < kNV; ++t) {
         const int m = lane + 64 * t;
         const int n0 = 2 * m;
-        int i0 = w * 512 + n0 - 512, i1 = i0 + 1;
+        int i0 = w * kHop + n0 - kHop, i1 = i0 + 1;
         i0 = i0 < 0 ? -i0 : (i0 >= kNR ? 2 * kNR - 2 - i0 : i0);
         i1 = i1 < 0 ? -i1 : (i1 >= kNR ? 2 * kNR - 2 - i1 : i1);
         const v2f ww = reinterpret_cast<const v2f*>(d.window)[m];
         v[t] = mk2(xs[i0] * ww[0], xs[i1] * ww[1]);
     }
-    fft512<false>(v, tw, tile[w], lane);
-    // Hermitian split in pair order: this lane gets bins k = lane + 64 t and 512 - k (t < 4); lane 0 also bin 256
-    v2f lo[4], hi[4], mid;
-    rfft_split_pairs(v, wkh, lane, lo, hi, mid);
+    G::Fft::template run<false>(v, tw, tile[w], lane);
+    // Hermitian split in pair order: this lane gets bins k = lane + 64 t and NC - k (t < NP); lane 0 also bin NC/2
+    v2f lo[kNP], hi[kNP], mid;
+    rfft_split_pairs<kNV>(v, wkh, lane, lo, hi, mid);
 
     if (WRITE_SPEC) {
         v2f* srow = reinterpret_cast<v2f*>(spec) + (b * 3 + w) * kBins;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < kNP; ++t) {
             srow[lane + 64 * t] = lo[t];
-            srow[512 - (lane + 64 * t)] = hi[t];
+            srow[G::kNC - (lane + 64 * t)] = hi[t];
         }
-        if (lane == 0) srow[256] = mid;
+        if (lane == 0) srow[G::kNC / 2] = mid;
     }
     if (WRITE_MEL) {
         // ---- P5: magnitude -> banded mel filterbank -> log1p; P6: rows are already (B,3,M)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < kNP; ++t) {
             magbuf[w][lane + 64 * t] = hypotf(lo[t][0], lo[t][1]);
-            magbuf[w][512 - (lane + 64 * t)] = hypotf(hi[t][0], hi[t][1]);
+            magbuf[w][G::kNC - (lane + 64 * t)] = hypotf(hi[t][0], hi[t][1]);
         }
-        if (lane == 0) magbuf[w][256] = hypotf(mid[0], mid[1]);
+        if (lane == 0) magbuf[w][G::kNC / 2] = hypotf(mid[0], mid[1]);
         wave_sync();
         float* mrow = mel + (b * 3 + w) * d.n_mels;
         for (int m = lane; m < d.n_mels; m += 64) {

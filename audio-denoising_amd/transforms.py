@@ -24,7 +24,7 @@ from torch import nn
 
 from . import _lib
 
-_N_FFT = 1024   # the FFT kernels are built for n_fft 1024 / hop 512 (mixed radix 1536 is SURVEY 8f-2)
+_N_FFTS = (1024, 1536)   # the one-wave FFT kernels: 512 = 8*8*8 and 768 = 4*4*4*12 complex points (hop = n_fft/2)
 
 
 def melscale_fbanks(n_freqs: int, f_min: float, f_max: float, n_mels: int, sample_rate: int) -> torch.Tensor:
@@ -126,8 +126,8 @@ class _PlanModule(nn.Module):
 def _check_fft_args(n_fft, win_length, hop_length):
     win_length = n_fft if win_length is None else win_length
     hop_length = win_length // 2 if hop_length is None else hop_length
-    if n_fft != _N_FFT or win_length != n_fft or hop_length != n_fft // 2:
-        raise NotImplementedError(f"the FFT kernels are built for n_fft=win_length={_N_FFT}, hop_length={_N_FFT // 2}; "
+    if n_fft not in _N_FFTS or win_length != n_fft or hop_length != n_fft // 2:
+        raise NotImplementedError(f"the FFT kernels are built for n_fft=win_length in {_N_FFTS} with hop_length=n_fft/2; "
                                   f"got n_fft={n_fft}, win_length={win_length}, hop_length={hop_length}")
     return n_fft, win_length, hop_length
 
@@ -179,15 +179,16 @@ class MelScale(_PlanModule):
         super().__init__()
         if norm is not None or mel_scale != "htk":
             raise NotImplementedError("only norm=None, mel_scale='htk' (what the reference uses)")
-        if n_stft != _N_FFT // 2 + 1:
-            raise NotImplementedError(f"n_stft must be {_N_FFT // 2 + 1}")
+        if 2 * (n_stft - 1) not in _N_FFTS:
+            raise NotImplementedError(f"n_stft must be one of {[n // 2 + 1 for n in _N_FFTS]}")
         self.n_mels, self.sample_rate, self.n_stft = n_mels, sample_rate, n_stft
         self.f_min = f_min
         self.f_max = f_max if f_max is not None else float(sample_rate // 2)
         self.register_buffer("fb", melscale_fbanks(n_stft, self.f_min, self.f_max, n_mels, sample_rate))
 
     def _plan_args(self):
-        return dict(sample_rate=self.sample_rate, n_fft=_N_FFT, hop=_N_FFT // 2, n_mels=self.n_mels, fb=self.fb)
+        n_fft = 2 * (self.n_stft - 1)
+        return dict(sample_rate=self.sample_rate, n_fft=n_fft, hop=n_fft // 2, n_mels=self.n_mels, fb=self.fb)
 
     def forward(self, specgram: torch.Tensor) -> torch.Tensor:
         _require(specgram, torch.float32, "MelScale")
@@ -213,8 +214,8 @@ class InverseMelScale(_PlanModule):
             raise NotImplementedError("only norm=None, mel_scale='htk' (what the reference uses)")
         if driver not in ("gels", "gelsy", "gelsd", "gelss"):
             raise ValueError(f'driver must be one of ["gels", "gelsy", "gelsd", "gelss"]. Found {driver}.')
-        if n_stft != _N_FFT // 2 + 1:
-            raise NotImplementedError(f"n_stft must be {_N_FFT // 2 + 1}")
+        if 2 * (n_stft - 1) not in _N_FFTS:
+            raise NotImplementedError(f"n_stft must be one of {[n // 2 + 1 for n in _N_FFTS]}")
         self.n_mels, self.sample_rate, self.n_stft, self.driver = n_mels, sample_rate, n_stft, driver
         self.f_min = f_min
         self.f_max = f_max if f_max is not None else float(sample_rate // 2)
@@ -222,7 +223,8 @@ class InverseMelScale(_PlanModule):
         self.register_buffer("fb", fb)
 
     def _plan_args(self):
-        return dict(sample_rate=self.sample_rate, n_fft=_N_FFT, hop=_N_FFT // 2, n_mels=self.n_mels, fb=self.fb)
+        n_fft = 2 * (self.n_stft - 1)
+        return dict(sample_rate=self.sample_rate, n_fft=n_fft, hop=n_fft // 2, n_mels=self.n_mels, fb=self.fb)
 
     def forward(self, melspec: torch.Tensor) -> torch.Tensor:
         _require(melspec, torch.float32, "InverseMelScale")

@@ -139,7 +139,7 @@ def main():
     np.savez(os.path.join(GOLD, "smear.npz"), coeff=np.float64(gs.coeff), **sm)
 
     # ---- G4: DSP fixtures from the restatement (UNPINNED) ---------------------
-    for tag, p in (("S", pipeline_ref.PARAMS_S), ("R2", pipeline_ref.PARAMS_R2)):
+    for tag, p in (("S", pipeline_ref.PARAMS_S), ("R2", pipeline_ref.PARAMS_R2), ("R1", pipeline_ref.PARAMS_R1)):
         g = torch.Generator().manual_seed(1234)
         B = 6
         frames = 0.1 * torch.randn(B, p.n_fft, generator=g)
@@ -170,6 +170,19 @@ def main():
     with torch.no_grad():
         y = st.push(sig, init_angles_per_hop=inits)
     np.savez(os.path.join(GOLD, "stream_S.npz"), signal=sig.numpy(), init_angles=torch.stack(inits).numpy(),
+             out=y.numpy(), ola=st.ola.numpy(), hx=st.hx.numpy())
+    # streaming at the app's own parameters (app3.py:29-33): 3 streams x 6 hops
+    p = pipeline_ref.PARAMS_R1
+    g = torch.Generator().manual_seed(199)
+    n_hops = 6
+    sig = 0.1 * torch.randn(3, p.n_fft + p.hop * (n_hops - 1), generator=g)
+    ga = torch.Generator().manual_seed(4321)
+    inits = [torch.rand(3, p.n_stft, 3, dtype=torch.complex64, generator=ga) for _ in range(n_hops)]
+    sd = model_ref.unflatten_weights(np.fromfile(os.path.join(GOLD, "weights_dari_tult2.bin"), dtype=np.float32))   # app3.py:13
+    st = pipeline_ref.StreamRef(sd, p, 3)
+    with torch.no_grad():
+        y = st.push(sig, init_angles_per_hop=inits)
+    np.savez(os.path.join(GOLD, "stream_R1.npz"), signal=sig.numpy(), init_angles=torch.stack(inits).numpy(),
              out=y.numpy(), ola=st.ola.numpy(), hx=st.hx.numpy())
     print("fixtures written to", GOLD)
     for fn in sorted(os.listdir(GOLD)):

@@ -242,3 +242,49 @@ def test_streaming_pipe_matches_oracle_with_one_hop_delay(lib, dsp):
     lib.dn_pipe_destroy(pipe)
     lib.dn_pipe_destroy(pipe_f)
     lib.dn_model_destroy(m)
+
+
+# ------------------------------------------------------------------ the app's own parameters: n_fft 1536 (768 = 4*4*4*12)
+P1 = pipeline_ref.PARAMS_R1
+
+
+@pytest.fixture(scope="module")
+def dsp_r1(lib):
+    fb = dsp_ref.melscale_fbanks(P1.n_stft, P1.n_mels, P1.sample_rate).numpy()
+    h = C.c_void_p()
+    lib.check(lib.dn_dsp_create(C.byref(DspCfg(P1.sample_rate, P1.n_fft, P1.hop, P1.n_mels)), emu.ptr(emu.f32(fb)), None,
+                                emu.ptr(emu.f32(torch.hann_window(P1.n_fft).numpy())), C.byref(h)))
+    yield h
+    lib.dn_dsp_destroy(h)
+
+
+def test_r1_stft_and_istft_mixed_radix(lib, dsp_r1):
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, P1.n_fft, generator=g)
+    spec = np.zeros((2, 3, P1.n_stft, 2), np.float32)
+    lib.check(lib.dn_stft(dsp_r1, emu.ptr(emu.f32(x.numpy())), emu.ptr(spec), 2, 0, None))
+    ref = dsp_ref.spectrogram(x, P1.n_fft, P1.hop).numpy()
+    got = (spec[..., 0] + 1j * spec[..., 1]).transpose(0, 2, 1)
+    assert np.abs(got - ref).max() <= 2e-6 * np.abs(ref).max() + 1e-5
+    wave = np.zeros((2, P1.n_fft), np.float32)
+    lib.check(lib.dn_istft(dsp_r1, emu.ptr(spec), emu.ptr(wave), 2, None))
+    assert np.abs(wave - x.numpy()).max() <= 2e-5
+
+
+def test_r1_process_frame_matches_oracle(lib, dsp_r1):
+    g = load_golden("dsp_R1.npz")
+    B = 2
+    m = make_model(lib, 4)
+    ws = np.zeros(lib.dn_workspace_bytes(dsp_r1, B) // 4 + 16, np.float32)
+    frames = emu.f32(g["frames"][:B])
+    hx = np.zeros((B, 17, 4), np.float32)
+    out = np.zeros((B, P1.n_fft), np.float32)
+    resid = np.zeros((B, 3, P1.n_mels), np.float32)
+    ia = g["init_angles"][:B].transpose(0, 2, 1)
+    ia = emu.f32(np.stack([ia.real, ia.imag], axis=-1))
+    lib.check(lib.dn_process_frame(m, dsp_r1, emu.ptr(frames), emu.ptr(hx), emu.ptr(out), emu.ptr(resid), emu.ptr(ia), 0, 0, 32, 0.99,
+                                   emu.ptr(ws), B, None))
+    lib.dn_model_destroy(m)
+    assert np.abs(resid - g["predicted_diff"][:B]).max() <= 1e-4
+    assert np.abs(hx - g["hx"][:B]).max() <= 1e-4
+    assert np.sqrt(np.mean((out - g["out"][:B]) ** 2)) <= 1e-3

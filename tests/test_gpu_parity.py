@@ -114,11 +114,16 @@ def _transforms(dev, p):
             T.GriffinLim(n_fft=p.n_fft, win_length=p.n_fft, hop_length=p.hop, window_fn=torch.hann_window, power=1.0).to(dev))
 
 
-@pytest.mark.parametrize("tag", ["S", "R2"])
-def test_transform_chain_as_the_app_calls_it(dev, tag):
-    """app3.py:188-213 written with this package's transforms in place of torchaudio's."""
+def _params(tag):
     from oracle import pipeline_ref
-    p = pipeline_ref.PARAMS_S if tag == "S" else pipeline_ref.PARAMS_R2
+    return {"S": pipeline_ref.PARAMS_S, "R1": pipeline_ref.PARAMS_R1, "R2": pipeline_ref.PARAMS_R2}[tag]
+
+
+@pytest.mark.parametrize("tag", ["S", "R2", "R1"])
+def test_transform_chain_as_the_app_calls_it(dev, tag):
+    """app3.py:188-213 written with this package's transforms in place of torchaudio's (R1 = the app's own
+    STFT_PARAMS, app3.py:29-33: n_fft 1536 -> the mixed-radix 768-point one-wave FFT)."""
+    p = _params(tag)
     g = load_golden(f"dsp_{tag}.npz")
     T0, M0T, M0I, GL = _transforms(dev, p)
     assert torch.equal(M0T.fb.cpu(), torch.from_numpy(g["fb"]))          # filterbank is bit-identical to the oracle's
@@ -182,11 +187,10 @@ def test_griffinlim_is_idempotent_on_a_consistent_spectrogram_and_seeded_rng_rep
 
 
 # ------------------------------------------------------------------ the fused hop
-@pytest.mark.parametrize("tag", ["S", "R2"])
+@pytest.mark.parametrize("tag", ["S", "R2", "R1"])
 def test_process_frame_matches_oracle_golden(dev, tag):
     from audio_denoising_amd.pipeline import Denoiser
-    from oracle import pipeline_ref
-    p = pipeline_ref.PARAMS_S if tag == "S" else pipeline_ref.PARAMS_R2
+    p = _params(tag)
     g = load_golden(f"dsp_{tag}.npz")
     dn = Denoiser(_model(dev, p.num_compressed_bins), p.sample_rate, p.n_fft, p.hop, p.n_mels)
     frames = torch.from_numpy(g["frames"]).to(dev)
@@ -315,3 +319,29 @@ def test_pipelined_stream_matches_oracle_golden_with_one_hop_delay(dev):
         of = psf.push(torch.from_numpy(q.cpu().numpy().astype(np.float32) / np.float32(32767)).to(dev))
         assert o16.dtype == torch.int16
         assert torch.equal(o16, (torch.clamp(of, -1, 1) * 32767).to(torch.int16))
+
+
+def test_app_parameters_streaming_serial_and_pipelined(dev):
+    """The reference app's own configuration (app3.py:13-33): 48 kHz, n_fft 1536, hop 768, 64 mels, checkpoint
+    GRUUNet2-dari_tult2 -- streamed through DenoiserStream (serial hops) and PipelinedStream (one launch per hop)."""
+    from audio_denoising_amd.pipeline import Denoiser, DenoiserStream, PipelinedStream
+    p = _params("R1")
+    g = load_golden("stream_R1.npz")
+    dn = Denoiser(_model(dev, 4, "dari_tult2"), p.sample_rate, p.n_fft, p.hop, p.n_mels)
+    sig = torch.from_numpy(g["signal"]).to(dev)
+    inits = [torch.from_numpy(a).to(dev) for a in g["init_angles"]]
+    st = DenoiserStream(dn, 3)
+    y = st.push(sig, init_angles_per_hop=inits).cpu().numpy()
+    assert y.shape == g["out"].shape and np.sqrt(np.mean((y - g["out"]) ** 2)) <= TOL_WAVE_RMS
+    assert np.abs(st.hx.cpu().numpy() - g["hx"]).max() <= 5e-4
+    ps = PipelinedStream(dn, 3)
+    outs = [ps.push(sig[:, i * p.hop:(i + 1) * p.hop].contiguous(), init_angles=inits[i - 1] if i >= 1 else None) for i in range(len(inits) + 1)]
+    outs.append(ps.flush())
+    y2 = torch.cat(outs[2:], 1).cpu().numpy()
+    assert np.sqrt(np.mean((y2 - g["out"]) ** 2)) <= TOL_WAVE_RMS
+    # size-independent property at the app's parameters: istft(stft(x)) == x for a full batch
+    from audio_denoising_amd import transforms as T
+    T0 = T.Spectrogram(power=None, n_fft=p.n_fft, win_length=p.n_fft, hop_length=p.hop).to(dev)
+    I0 = T.InverseSpectrogram(n_fft=p.n_fft, win_length=p.n_fft, hop_length=p.hop).to(dev)
+    x = torch.randn(256, p.n_fft, generator=torch.Generator().manual_seed(3)).to(dev)
+    assert (I0(T0(x)) - x).abs().max().item() <= 3e-5

@@ -48,8 +48,10 @@ def test_library_is_a_gfx950_code_object(built_lib):
 def test_bad_arguments_fail_with_messages_not_crashes(built_lib):
     from audio_denoising_amd._lib import DnError, DspCfg
     h = ctypes.c_void_p()
-    rc = built_lib.dn_dsp_create(ctypes.byref(DspCfg(48000, 1536, 768, 64)), None, None, None, ctypes.byref(h))
-    assert rc == -2 and b"1024" in built_lib.dn_last_error()      # mixed-radix n_fft=1536 not built yet: loud, not silent
+    rc = built_lib.dn_dsp_create(ctypes.byref(DspCfg(48000, 2048, 1024, 64)), None, None, None, ctypes.byref(h))
+    assert rc == -2 and b"1536" in built_lib.dn_last_error()      # only n_fft 1024 / 1536 are built: loud, not silent
+    rc = built_lib.dn_dsp_create(ctypes.byref(DspCfg(48000, 1536, 512, 64)), None, None, None, ctypes.byref(h))
+    assert rc == -2                                               # hop must be n_fft/2
     with pytest.raises(DnError):
         built_lib.check(built_lib.dn_cell_forward(None, None, None, None, None, 1, 1, 64, 4, None))
     assert built_lib.dn_workspace_bytes(None, 4) == 0
@@ -97,8 +99,9 @@ def test_cpu_tensors_and_unsupported_configs_fail_loudly():
     from audio_denoising_amd import transforms as T
     with pytest.raises(RuntimeError, match="CUDA"):
         T.Spectrogram(power=None, n_fft=1024, win_length=1024, hop_length=512)(torch.zeros(1, 1024))
+    T.Spectrogram(power=None, n_fft=1536, win_length=1536, hop_length=768)        # app3.py:29-33: supported
     with pytest.raises(NotImplementedError):
-        T.Spectrogram(power=None, n_fft=1536, win_length=1536, hop_length=768)
+        T.Spectrogram(power=None, n_fft=2048, win_length=2048, hop_length=1024)
     with pytest.raises(ValueError):
         T.GriffinLim(n_fft=1024, momentum=1.5)
 
@@ -106,10 +109,10 @@ def test_cpu_tensors_and_unsupported_configs_fail_loudly():
 def test_transform_constructors_build_the_reference_filterbank():
     from audio_denoising_amd import transforms as T
     from oracle import dsp_ref
-    for sr, n_mels in ((16000, 80), (48000, 64)):
-        m = T.MelScale(n_mels=n_mels, n_stft=513, sample_rate=sr)
-        assert torch.equal(m.fb, dsp_ref.melscale_fbanks(513, n_mels, sr))
-        inv = T.InverseMelScale(n_mels=n_mels, n_stft=513, sample_rate=sr)
+    for sr, n_mels, n_stft in ((16000, 80, 513), (48000, 64, 513), (48000, 64, 769)):
+        m = T.MelScale(n_mels=n_mels, n_stft=n_stft, sample_rate=sr)
+        assert torch.equal(m.fb, dsp_ref.melscale_fbanks(n_stft, n_mels, sr))
+        inv = T.InverseMelScale(n_mels=n_mels, n_stft=n_stft, sample_rate=sr)
         assert torch.equal(inv.fb, m.fb)
     assert torch.equal(T.GriffinLim(n_fft=1024, win_length=1024, hop_length=512, power=1.0).window, torch.hann_window(1024))
 
