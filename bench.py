@@ -43,11 +43,17 @@ PEAK_FP32_TFLOPS = 157.3                                          # MI355X_MICRO
 PEAK_HBM_GBS = 8000.0
 
 
-def build_denoiser(dev):
+# parameter presets: S = BASELINE.json's synthetic config (the metric); R1 = the reference app's own (app3.py:13-33);
+# R2 = server.py:166-170.  Only S is the headline; the others are reported by `--preset` for DESIGN.md.
+PRESETS = {"S": (16000, 1024, 512, 80, "dari_tult"), "R1": (48000, 1536, 768, 64, "dari_tult2"), "R2": (48000, 1024, 512, 64, "dari_tult")}
+
+
+def build_denoiser(dev, preset="S"):
     from audio_denoising_amd.gruunet2 import GRUUNet2
     from audio_denoising_amd.pipeline import Denoiser
-    blob = np.fromfile(os.path.join(REPO, "tests", "golden", "weights_dari_tult.bin"), dtype=np.float32)
-    model = GRUUNet2(5, 1, (17, 17, 17, 17), (3, 3, 3, 3), (2, 2, 2, 2), (1, 1, 1, 1))
+    sr, n_fft, hop, n_mels, ckpt = PRESETS[preset]
+    blob = np.fromfile(os.path.join(REPO, "tests", "golden", f"weights_{ckpt}.bin"), dtype=np.float32)
+    model = GRUUNet2(n_mels // 16, 1, (17, 17, 17, 17), (3, 3, 3, 3), (2, 2, 2, 2), (1, 1, 1, 1))
     keys = list(model.state_dict().keys())
     sd, off = {}, 0
     for k in keys:
@@ -56,7 +62,7 @@ def build_denoiser(dev):
         off += n
     model.load_state_dict(sd)
     model.eval().to(dev)
-    return Denoiser(model, SR, N_FFT, HOP, N_MELS, n_iter=GL_ITERS)
+    return Denoiser(model, sr, n_fft, hop, n_mels, n_iter=GL_ITERS)
 
 
 def staged_kernel_times(dn, frames, hx, steps):
@@ -128,6 +134,46 @@ def cpu_baseline(budget_s=20.0):
             "batch1_value": round(res[1][0], 1)}
 
 
+def side_measurement(args, dn, B, dev):
+    """Extra, non-headline measurements (single GPU): other parameter presets and the streaming mode."""
+    from audio_denoising_amd.pipeline import HopPipeline, PipelinedStream
+    g = torch.Generator().manual_seed(1234)
+    out = torch.empty(B, dn.n_fft, device=dev)
+    hx = dn.init_hx(B)
+    if args.stream:
+        ps = PipelinedStream(dn, B)
+        hop = (0.1 * torch.randn(B, dn.hop, generator=g)).to(dev)
+
+        def step(i):
+            ps.push(hop)
+        fin = ps.flush
+    else:
+        frames = (0.1 * torch.randn(B, dn.n_fft, generator=g)).to(dev)
+        pipe = HopPipeline(dn, B)
+
+        def step(i):
+            pipe.submit(frames, hx, out, seed=1000 + i)
+        fin = pipe.flush
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < 0.5:
+        for i in range(50):
+            step(i)
+        torch.cuda.synchronize()
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    fin()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    print(json.dumps({"metric": "frames/s (side measurement, not the headline)", "preset": args.preset, "mode": "stream" if args.stream else "frames",
+                      "value": round(B * args.steps / el, 1), "unit": "frames/s", "streams": B, "ms_per_step": round(1e3 * el / args.steps, 4),
+                      "n_fft": dn.n_fft, "hop": dn.hop, "n_mels": dn.n_mels, "sample_rate": dn.sample_rate,
+                      "realtime_streams_per_gpu": int(B * args.steps / el / (dn.sample_rate / dn.hop))}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -135,7 +181,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=BATCH, help="streams per GPU (the metric is quoted at 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--serial", action="store_true", help="one hop at a time on one stream (dn_process_frame) instead of the two-stream pipeline")
+    ap.add_argument("--serial", action="store_true", help="one hop at a time, 3 launches (dn_process_frame) instead of the software-pipelined hop")
+    ap.add_argument("--preset", choices=sorted(PRESETS), default="S", help="S = the metric's config; R1/R2 = the reference's own parameters (extra measurements)")
+    ap.add_argument("--stream", action="store_true", help="streaming mode (BASELINE config 5): pipe-owned ring/overlap-add/hx state, one hop of new samples per step")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -157,8 +205,10 @@ def main():
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from audio_denoising_amd.shard import shard_range
-    dn = build_denoiser(dev)
+    dn = build_denoiser(dev, args.preset)
     B = args.batch
+    if args.preset != "S" or args.stream:
+        return side_measurement(args, dn, B, dev)
     lo, hi = shard_range(B * world, world, rank)          # this rank's global stream ids
     g = torch.Generator().manual_seed(1234 + rank)
     frames = (0.1 * torch.randn(B, N_FFT, generator=g)).to(dev)
