@@ -327,6 +327,7 @@ void dn_model_destroy(dn_model* m) {
 
 int dn_cell_forward(const dn_model* m, const float* x, const float* hx_in, float* out, float* hx_out, int32_t B,
                     int32_t T, int32_t F, int32_t C, void* stream) {
+    if (B == 0) return DN_OK;      // empty batch: nothing to do (pointers of empty tensors are null)
     if (!m || !x || !out || !hx_out) return fail(DN_ERR_INVALID, "dn_cell_forward: null argument");
     if (B < 0 || T < 0) return fail(DN_ERR_INVALID, "dn_cell_forward: negative size");
     if (C < 1 || C > dn::kMaxC) return fail(DN_ERR_UNSUPPORTED, "compressed bins C must be in 1.." + std::to_string(dn::kMaxC));
@@ -459,6 +460,7 @@ int dn_dsp_get_tables(const dn_dsp* d, float* fb, float* pinv, float* window) {
 }
 
 int dn_stft(const dn_dsp* d, const float* frames, float* spec, int32_t B, uint32_t flags, void* stream) {
+    if (B == 0) return DN_OK;      // empty batch: nothing to do (pointers of empty tensors are null)
     if (!d || !frames || !spec) return fail(DN_ERR_INVALID, "dn_stft: null argument");
     if (B < 0) return fail(DN_ERR_INVALID, "dn_stft: negative batch");
     if (B == 0) return DN_OK;
@@ -467,6 +469,7 @@ int dn_stft(const dn_dsp* d, const float* frames, float* spec, int32_t B, uint32
 }
 
 int dn_stft_mel_log1p(const dn_dsp* d, const float* frames, float* mel, float* peak, int32_t B, uint32_t flags, void* stream) {
+    if (B == 0) return DN_OK;      // empty batch: nothing to do (pointers of empty tensors are null)
     if (!d || !frames || !mel) return fail(DN_ERR_INVALID, "dn_stft_mel_log1p: null argument");
     if (d->cfg.n_mels <= 0) return fail(DN_ERR_INVALID, "plan was created without mel stages");
     if (B < 0) return fail(DN_ERR_INVALID, "dn_stft_mel_log1p: negative batch");
@@ -504,6 +507,7 @@ int dn_residual_invmel(const dn_dsp* d, const float* x, const float* diff, float
 
 int dn_griffinlim(const dn_dsp* d, const float* mag, const float* init_angles, uint64_t seed, uint64_t stream_id0,
                   const float* scale, float* wave, int32_t B, int32_t n_iter, float momentum, void* stream) {
+    if (B == 0) return DN_OK;      // empty batch: nothing to do (pointers of empty tensors are null)
     if (!d || !mag || !wave) return fail(DN_ERR_INVALID, "dn_griffinlim: null argument");
     if (B < 0 || n_iter < 0) return fail(DN_ERR_INVALID, "dn_griffinlim: negative size");
     if (!(momentum >= 0.0f && momentum < 1.0f)) return fail(DN_ERR_INVALID, "momentum must be in [0, 1)");
@@ -514,6 +518,7 @@ int dn_griffinlim(const dn_dsp* d, const float* mag, const float* init_angles, u
 
 int dn_synthesis(const dn_dsp* d, const float* x, const float* diff, const float* init_angles, uint64_t seed, uint64_t stream_id0,
                  const float* scale, float* wave, int32_t B, int32_t n_iter, float momentum, void* stream) {
+    if (B == 0) return DN_OK;      // empty batch: nothing to do (pointers of empty tensors are null)
     if (!d || !x || !diff || !wave) return fail(DN_ERR_INVALID, "dn_synthesis: null argument");
     if (d->cfg.n_mels <= 0) return fail(DN_ERR_INVALID, "plan was created without mel stages");
     if (B < 0 || n_iter < 0) return fail(DN_ERR_INVALID, "dn_synthesis: negative size");
@@ -524,6 +529,7 @@ int dn_synthesis(const dn_dsp* d, const float* x, const float* diff, const float
 }
 
 int dn_istft(const dn_dsp* d, const float* spec, float* wave, int32_t B, void* stream) {
+    if (B == 0) return DN_OK;      // empty batch: nothing to do (pointers of empty tensors are null)
     if (!d || !spec || !wave) return fail(DN_ERR_INVALID, "dn_istft: null argument");
     if (B < 0) return fail(DN_ERR_INVALID, "dn_istft: negative batch");
     if (B == 0) return DN_OK;
@@ -545,6 +551,7 @@ size_t dn_workspace_bytes(const dn_dsp* d, int32_t B) {
 int dn_process_frame(const dn_model* m, const dn_dsp* d, const float* frames, float* hx, float* out, float* mel_residual_out,
                      const float* init_angles, uint64_t seed, uint64_t stream_id0, int32_t n_iter, float momentum,
                      void* workspace, int32_t B, void* stream) {
+    if (B == 0) return DN_OK;      // empty batch: nothing to do (pointers of empty tensors are null)
     if (!m || !d || !frames || !hx || !out || !workspace) return fail(DN_ERR_INVALID, "dn_process_frame: null argument");
     if (d->cfg.n_mels <= 0 || d->cfg.n_mels % 16) return fail(DN_ERR_INVALID, "n_mels must be a positive multiple of 16");
     if (B < 0 || n_iter < 0) return fail(DN_ERR_INVALID, "dn_process_frame: negative size");
@@ -572,6 +579,7 @@ int dn_process_frame(const dn_model* m, const dn_dsp* d, const float* frames, fl
 int dn_stream_step(const dn_model* m, const dn_dsp* d, const float* hop_in, float* ring, float* ola, float* hx, float* hop_out,
                    const float* init_angles, uint64_t seed, uint64_t stream_id0, int32_t n_iter, float momentum, void* workspace,
                    int32_t B, void* stream) {
+    if (B == 0) return DN_OK;      // empty batch: nothing to do (pointers of empty tensors are null)
     if (!hop_in || !ring || !ola || !hop_out || !workspace) return fail(DN_ERR_INVALID, "dn_stream_step: null argument");
     if (B < 0) return fail(DN_ERR_INVALID, "dn_stream_step: negative batch");
     if (B == 0) return DN_OK;

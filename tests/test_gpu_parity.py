@@ -345,3 +345,87 @@ def test_app_parameters_streaming_serial_and_pipelined(dev):
     I0 = T.InverseSpectrogram(n_fft=p.n_fft, win_length=p.n_fft, hop_length=p.hop).to(dev)
     x = torch.randn(256, p.n_fft, generator=torch.Generator().manual_seed(3)).to(dev)
     assert (I0(T0(x)) - x).abs().max().item() <= 3e-5
+
+
+def test_empty_batch_is_a_no_op(dev):
+    from audio_denoising_amd.pipeline import Denoiser
+    p = _params("S")
+    m = _model(dev, 5)
+    out, hx = m(torch.zeros(0, 3, 80, device=dev))
+    assert out.shape == (0, 3, 80) and hx.shape == (0, 17, 5)
+    dn = Denoiser(m, p.sample_rate, p.n_fft, p.hop, p.n_mels)
+    o, h = dn.process_frame(torch.zeros(0, p.n_fft, device=dev))
+    assert o.shape == (0, p.n_fft) and h.shape == (0, 17, 5)
+
+
+def test_one_model_shared_by_concurrent_threads(dev):
+    """The reference shares ONE model object between all WebRTC worker threads (st.cache_resource, app3.py:46,499-505),
+    each session with private hx/buffers.  Handles are immutable, so concurrent forwards from threads on their own
+    HIP streams must give each thread exactly its single-threaded result."""
+    import threading
+    g = load_golden("cell_dari_tult_chain20_F80.npz")
+    m = _model(dev, 5)
+    xs = torch.from_numpy(g["x"]).to(dev)                       # (20, 8, 3, 80)
+    m(xs[0])                                                    # build the native handle once
+    results, errors = {}, []
+
+    def worker(tid):
+        try:
+            st = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(st):
+                hx, outs = None, []
+                for h in range(20):
+                    o, hx = m(xs[h, tid:tid + 2].contiguous(), hx)
+                    outs.append(o)
+                st.synchronize()
+            results[tid] = (torch.stack(outs).cpu().numpy(), hx.cpu().numpy())
+        except Exception as e:          # pragma: no cover
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in (0, 2, 4, 6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for tid, (o, hx) in results.items():
+        assert np.abs(o - g["out"][:, tid:tid + 2]).max() <= TOL_RESIDUAL
+        assert np.abs(hx - g["hx_final"][tid:tid + 2]).max() <= TOL_RESIDUAL
+
+
+def test_pipelined_hops_are_graph_capturable(dev):
+    """BASELINE config 5 asks for a hipGraph-captured step: the pipelined hop is one plain kernel launch on the
+    caller's stream (no allocation, no sync, no events), so a run of hops captures into a graph and replays."""
+    from audio_denoising_amd.pipeline import Denoiser, HopPipeline
+    p = _params("S")
+    dn = Denoiser(_model(dev, 5), p.sample_rate, p.n_fft, p.hop, p.n_mels)
+    B, n = 64, 4
+    gen = torch.Generator().manual_seed(17)
+    frames = [(0.1 * torch.randn(B, p.n_fft, generator=gen)).to(dev) for _ in range(n)]
+    outs = [torch.empty(B, p.n_fft, device=dev) for _ in range(n)]
+    hx = dn.init_hx(B)
+    pipe = HopPipeline(dn, B)
+
+    def run():
+        for i in range(n):
+            pipe.submit(frames[i], hx, outs[i], seed=40 + i, stream_id0=0)
+        pipe.flush()
+
+    run()                                           # eager reference (also warms every code path)
+    torch.cuda.synchronize()
+    eager = [o.clone() for o in outs]
+    hx_eager = hx.clone()
+    hx.zero_()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            run()
+    for o in outs:
+        o.zero_()
+    hx.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(hx, hx_eager)
+    for a, b in zip(eager, outs):
+        assert torch.equal(a, b)
