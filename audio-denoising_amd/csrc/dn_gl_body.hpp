@@ -1,5 +1,7 @@
 // dn_gl_body.hpp -- device body of the Griffin-Lim stage (see dn_griffinlim.hip for the description).
 #pragma once
+#include <type_traits>
+
 #include "dn_internal.hpp"
 #include "dn_wavefft.hpp"
 
@@ -152,6 +154,10 @@ __device__ __forceinline__ void gl_body(char* smem, const DspDev& d, const float
 
     if (FROM_MEL) __syncthreads();        // the prologue scratch becomes the overlap-add lines
 
+    // The iteration loop is instantiated once per column (W is a compile-time constant inside): the overlap-add
+    // stores and every other column-dependent choice become straight-line code instead of per-value predicates.
+    auto iterate = [&](auto wc) {
+    constexpr int W = decltype(wc)::value;
     v2f v[kNV], xlo[kNP], xhi[kNP], xmid;
     for (int it = 0;; ++it) {
         // ---- istft of angles * magnitude: Hermitian merge, inverse FFT, synthesis window, overlap-add lines
@@ -168,11 +174,10 @@ __device__ __forceinline__ void gl_body(char* smem, const DspDev& d, const float
         {
             // column 1 -> y1[n]; column 0 keeps its second half -> yo[n-H]; column 2 its first half -> yo[n+H]
             // (the other halves fall outside the samples the istft trim keeps and are simply not stored)
-            float* ydst = w == 1 ? y1 : (w == 0 ? yo - kHop : yo + kHop);
-            const int t_lo = w == 0 ? kNP : 0, t_hi = w == 2 ? kNP : kNV;
+            float* ydst = W == 1 ? y1 : (W == 0 ? yo - kHop : yo + kHop);
+            constexpr int t_lo = W == 0 ? kNP : 0, t_hi = W == 2 ? kNP : kNV;
 #pragma unroll
-            for (int t = 0; t < kNV; ++t)
-                if (t >= t_lo && t < t_hi) *reinterpret_cast<v2f*>(ydst + 2 * (lane + 64 * t)) = v[t] * wsyn[t];
+            for (int t = t_lo; t < t_hi; ++t) *reinterpret_cast<v2f*>(ydst + 2 * (lane + 64 * t)) = v[t] * wsyn[t];
         }
         __syncthreads();
         if (it == n_iter) {
@@ -224,6 +229,10 @@ __device__ __forceinline__ void gl_body(char* smem, const DspDev& d, const float
         }
         update(xmid, pmid, amid);
     }
+    };
+    if (w == 0) iterate(std::integral_constant<int, 0>{});
+    else if (w == 1) iterate(std::integral_constant<int, 1>{});
+    else iterate(std::integral_constant<int, 2>{});
 }
 
 }  // namespace dn
