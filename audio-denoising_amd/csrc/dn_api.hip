@@ -111,8 +111,9 @@ struct BiasSet {
 struct dn_model {
     dn_model_cfg cfg;
     std::vector<float> w;      // the caller's flat state_dict
-    DevArena packed;           // data-channel weights, [c][k][o]
+    DevArena packed;           // MFMA weight fragments (fp32 and bf16), recurrent and last-level weights
     size_t off_down[4], off_gh, off_up[4];
+    size_t offb_down[4], offb_up[3];
     std::mutex mu;
     std::map<int, BiasSet*> bias;   // per number of compressed bins C
 };
@@ -206,6 +207,8 @@ int build_bias(dn_model* m, int C, BiasSet** out) {
     for (int l = 0; l < 4; ++l) {
         bs->view.w_down[l] = m->packed.ptr<float>(m->off_down[l]);
         bs->view.w_up[l] = m->packed.ptr<float>(m->off_up[l]);
+        bs->view.wb_down[l] = m->packed.ptr<char>(m->offb_down[l]);
+        if (l < 3) bs->view.wb_up[l] = m->packed.ptr<char>(m->offb_up[l]);
         bs->view.bt_down[l] = bs->arena.ptr<float>(o_down[l]);
         bs->view.bt_up[l] = bs->arena.ptr<float>(o_up[l]);
     }
@@ -309,6 +312,42 @@ int dn_model_create(const float* weights, size_t n_floats, const dn_model_cfg* c
             for (int k = 0; k < 3; ++k) p[(size_t)c * 3 + k] = W[sl.uw[3] + (size_t)c * 3 + k];
         m->off_up[3] = m->packed.add(p.data(), p.size() * sizeof(float));
     }
+    // bf16 fragments for v_mfma_f32_16x16x32_bf16 (config 3): lane l of k-step ks supplies 8 consecutive K slots
+    // 8 (l >> 4) + j = channels of one tap (level 0: the taps themselves); round to nearest even.
+    auto bf16 = [](float f) -> uint16_t {
+        uint32_t u; memcpy(&u, &f, 4);
+        u += 0x7FFFu + ((u >> 16) & 1u);
+        return (uint16_t)(u >> 16);
+    };
+    for (int l = 0; l < 4; ++l) {
+        const int cd = l == 0 ? 1 : 17, ct = cd + 6, co = l == 3 ? 51 : 17, ks_n = cd == 1 ? 1 : 3, mtiles = (co + 15) / 16;
+        std::vector<uint16_t> p((size_t)mtiles * ks_n * 64 * 8, 0);
+        for (int mt = 0; mt < mtiles; ++mt)
+            for (int ks = 0; ks < ks_n; ++ks)
+                for (int ln = 0; ln < 64; ++ln)
+                    for (int j = 0; j < 8; ++j) {
+                        const int o = mt * 16 + (ln & 15), q = ln >> 4;
+                        const int tap = cd == 1 ? j : ks, c = cd == 1 ? 0 : 8 * q + j;
+                        const bool ok = o < co && (cd == 1 ? (q == 0 && j < 3) : c < cd);
+                        if (ok) p[(((size_t)mt * ks_n + ks) * 64 + ln) * 8 + j] = bf16(W[sl.dw[l] + ((size_t)o * ct + c) * 3 + tap]);
+                    }
+        m->offb_down[l] = m->packed.add(p.data(), p.size() * sizeof(uint16_t));
+    }
+    for (int l = 0; l < 3; ++l) {
+        const int parts = l == 0 ? 1 : 2, co = 17;
+        static const int kTapOfSet[3] = {1, 2, 0};
+        std::vector<uint16_t> p((size_t)2 * 3 * parts * 64 * 8, 0);
+        for (int mt = 0; mt < 2; ++mt)
+            for (int set = 0; set < 3; ++set)
+                for (int part = 0; part < parts; ++part)
+                    for (int ln = 0; ln < 64; ++ln)
+                        for (int j = 0; j < 8; ++j) {
+                            const int o = mt * 16 + (ln & 15), cp = 8 * (ln >> 4) + j, c = part * 17 + cp;
+                            if (o < co && cp < 17)
+                                p[((((size_t)mt * 3 + set) * parts + part) * 64 + ln) * 8 + j] = bf16(W[sl.uw[l] + ((size_t)c * co + o) * 3 + kTapOfSet[set]]);
+                        }
+        m->offb_up[l] = m->packed.add(p.data(), p.size() * sizeof(uint16_t));
+    }
     hipError_t e = m->packed.upload();
     if (e != hipSuccess) { m->packed.release(); delete m; return fail(DN_ERR_HIP, std::string("weight upload: ") + hipGetErrorString(e)); }
     BiasSet* bs = nullptr;
@@ -340,6 +379,20 @@ int dn_cell_forward(const dn_model* m, const float* x, const float* hx_in, float
     if (rc != DN_OK) return rc;
     dn::launch_cell(bs->view, x, hx_in, out, hx_out, B, T, C, as_stream(stream));
     return check_launch("cell_kernel");
+}
+
+int dn_cell_forward_bf16(const dn_model* m, const float* x, const float* hx_in, float* out, float* hx_out, int32_t B,
+                         int32_t T, int32_t F, int32_t C, void* stream) {
+    if (B == 0) return DN_OK;
+    if (!m || !x || !out || !hx_out) return fail(DN_ERR_INVALID, "dn_cell_forward_bf16: null argument");
+    if (B < 0 || T < 0) return fail(DN_ERR_INVALID, "dn_cell_forward_bf16: negative size");
+    if (C < 1 || C > dn::kMaxC) return fail(DN_ERR_UNSUPPORTED, "compressed bins C must be in 1.." + std::to_string(dn::kMaxC));
+    if (F != 16 * C) return fail(DN_ERR_INVALID, "need F == 16*C");
+    BiasSet* bs = nullptr;
+    int rc = build_bias(const_cast<dn_model*>(m), C, &bs);
+    if (rc != DN_OK) return rc;
+    dn::launch_cell_bf16(bs->view, x, hx_in, out, hx_out, B, T, C, as_stream(stream));
+    return check_launch("cell_kernel_bf16");
 }
 
 int dn_dsp_create(const dn_dsp_cfg* cfg, const float* fb_in, const float* pinv_in, const float* window_in, dn_dsp** out) {

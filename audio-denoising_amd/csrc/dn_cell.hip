@@ -36,9 +36,23 @@ __global__ __launch_bounds__(kCellWaves * 64) void cell_kernel(CellDev cd, const
     cell_body<kCellWaves>(smem, cd, x, hx_in, out, hx_out, T, C, blockIdx.x, threadIdx.x);
 }
 
+// BASELINE config 3: the same forward with bf16 MFMA conv tiles (v_mfma_f32_16x16x32_bf16; conv inputs and weights
+// rounded to bf16, fp32 accumulate; the recurrent gate conv, the GRU math and the last decoder level stay fp32).
+__global__ __launch_bounds__(kCellWaves * 64) void cell_kernel_bf16(CellDev cd, const float* __restrict__ x,
+                                                                   const float* __restrict__ hx_in, float* __restrict__ out,
+                                                                   float* __restrict__ hx_out, int T, int C) {
+    __shared__ __attribute__((aligned(16))) char smem[kCellSmem];
+    cell_body<kCellWaves, true>(smem, cd, x, hx_in, out, hx_out, T, C, blockIdx.x, threadIdx.x);
+}
+
 void launch_cell(const CellDev& c, const float* x, const float* hx_in, float* out, float* hx_out, int B, int T,
                  int C, hipStream_t st) {
     hipLaunchKernelGGL(cell_kernel, dim3(B), dim3(kCellWaves * 64), 0, st, c, x, hx_in, out, hx_out, T, C);
+}
+
+void launch_cell_bf16(const CellDev& c, const float* x, const float* hx_in, float* out, float* hx_out, int B, int T,
+                      int C, hipStream_t st) {
+    hipLaunchKernelGGL(cell_kernel_bf16, dim3(B), dim3(kCellWaves * 64), 0, st, c, x, hx_in, out, hx_out, T, C);
 }
 
 }  // namespace dn

@@ -1,5 +1,7 @@
 // dn_cell_body.hpp -- device body of the GRUUNet2 forward (see dn_cell.hip for the description).
 #pragma once
+#include <dn_cpx.hpp>
+
 #include "dn_internal.hpp"
 
 namespace dn {
@@ -65,6 +67,131 @@ __device__ __forceinline__ void mconv_down(const float* __restrict__ afrag, cons
                 for (int r = 0; r < 4; ++r) {
                     const int o = (mt0 + mi) * 16 + q * 4 + r;
                     if (o < COUT) out[((size_t)t * COUT + o) * lout + p] = fmaxf(acc[mi][r], 0.0f);
+                }
+        }
+    }
+}
+
+// ---- bf16 variants (BASELINE config 3): conv inputs and weights rounded to bf16, fp32 accumulate, on
+// v_mfma_f32_16x16x32_bf16.  One k-step = 32 K slots = channels 8 q + j (q = lane >> 4, j = 0..7) of one tap, so a
+// 17-channel level needs 3 k-steps instead of 15; activations stay fp32 in LDS and are rounded when the B fragment is built.
+__device__ __forceinline__ f32x4 mfma16_bf16(const bf16x8& a, const bf16x8& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+template <int NW, int CIN, int COUT, int MT>
+__device__ __forceinline__ void mconv_down_bf16(const void* __restrict__ afrag, const float* __restrict__ bt, const float* in,
+                                                float* out, int lout, int tt, int wv, int lane) {
+    constexpr int KS = CIN == 1 ? 1 : 3;
+    constexpr int MTILES = (COUT + 15) / 16;
+    constexpr int MG = MTILES / MT;
+    const bf16x8* af8 = static_cast<const bf16x8*>(afrag);
+    const int lin = 2 * lout, items = tt * lout, ntiles = (items + 15) >> 4;
+    const int q = lane >> 4, jl = lane & 15;
+    for (int tile = wv; tile < ntiles * MG; tile += NW) {
+        const int nt = tile % ntiles, mt0 = (tile / ntiles) * MT;
+        const int item = nt * 16 + jl;
+        const bool valid = item < items;
+        const int itc = valid ? item : 0;
+        const int t = itc / lout, p = itc - t * lout;
+        f32x4 acc[MT];
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = (mt0 + mi) * 16 + q * 4 + r;
+                acc[mi][r] = o < COUT ? bt[o * lout + p] : 0.0f;
+            }
+        if (CIN == 1) {
+            bf16x8 b;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bool ok = q == 0 && j < 3 && !(j == 0 && p == 0);
+                b[j] = f2bf(ok ? in[t * lin + 2 * p - 1 + j] : 0.0f);
+            }
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) acc[mi] = mfma16_bf16(af8[((mt0 + mi) * KS) * 64 + lane], b, acc[mi]);
+        } else {
+            const float* base = in + (size_t)t * CIN * lin + 2 * p - 1;
+#pragma unroll
+            for (int tap = 0; tap < 3; ++tap) {
+                bf16x8 b;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int c = 8 * q + j;
+                    float x = base[min(c, CIN - 1) * lin + tap];
+                    if (c >= CIN || (tap == 0 && p == 0)) x = 0.0f;
+                    b[j] = f2bf(x);
+                }
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi) acc[mi] = mfma16_bf16(af8[((mt0 + mi) * KS + tap) * 64 + lane], b, acc[mi]);
+            }
+        }
+        if (valid) {
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = (mt0 + mi) * 16 + q * 4 + r;
+                    if (o < COUT) out[((size_t)t * COUT + o) * lout + p] = fmaxf(acc[mi][r], 0.0f);
+                }
+        }
+    }
+}
+
+template <int NW, bool SKIP, int MT>
+__device__ __forceinline__ void mconv_up_bf16(const void* __restrict__ afrag, const float* __restrict__ bt, const float* a,
+                                              const float* skip, float* out, int l, int tt, int wv, int lane) {
+    constexpr int PARTS = SKIP ? 2 : 1;
+    constexpr int MTILES = 2, MG = MTILES / MT;
+    const bf16x8* af8 = static_cast<const bf16x8*>(afrag);
+    const int lo = 2 * l, items = tt * l, ntiles = (items + 15) >> 4;
+    const int q = lane >> 4, jl = lane & 15;
+    for (int tile = wv; tile < ntiles * MG; tile += NW) {
+        const int nt = tile % ntiles, mt0 = (tile / ntiles) * MT;
+        const int item = nt * 16 + jl;
+        const bool valid = item < items;
+        const int itc = valid ? item : 0;
+        const int t = itc / l, i = itc - t * l;
+        const bool has_next = i + 1 < l;
+        f32x4 ev[MT], od[MT];
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = (mt0 + mi) * 16 + q * 4 + r;
+                ev[mi][r] = o < kHidden ? bt[o * lo + 2 * i] : 0.0f;
+                od[mi][r] = o < kHidden ? bt[o * lo + 2 * i + 1] : 0.0f;
+            }
+#pragma unroll
+        for (int part = 0; part < PARTS; ++part) {
+            const float* src = (part == 0 ? a : skip) + (size_t)t * kHidden * l + i;
+            bf16x8 x0, x1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = 8 * q + j;
+                const bool ok = c < kHidden;
+                const float* sc = src + min(c, kHidden - 1) * l;
+                x0[j] = f2bf(ok ? sc[0] : 0.0f);
+                x1[j] = f2bf(ok && has_next ? sc[1] : 0.0f);
+            }
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) {
+                const bf16x8* am = af8 + ((size_t)(mt0 + mi) * 3 * PARTS + part) * 64 + lane;    // [mt][set][part][64]
+                ev[mi] = mfma16_bf16(am[0 * PARTS * 64], x0, ev[mi]);
+                od[mi] = mfma16_bf16(am[1 * PARTS * 64], x0, od[mi]);
+                od[mi] = mfma16_bf16(am[2 * PARTS * 64], x1, od[mi]);
+            }
+        }
+        if (valid) {
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = (mt0 + mi) * 16 + q * 4 + r;
+                    if (o < kHidden)
+                        *reinterpret_cast<float2*>(out + ((size_t)t * kHidden + o) * lo + 2 * i) =
+                            make_float2(fmaxf(ev[mi][r], 0.0f), fmaxf(od[mi][r], 0.0f));
                 }
         }
     }
@@ -159,7 +286,7 @@ constexpr int kCellLdsFloats = 4 + 3 * 16 * kMaxC + 3 * 17 * 14 * kMaxC * 2 + 3 
 constexpr int kCellSmem = 4 * kCellLdsFloats;      // 34,976 B
 
 // One workgroup of NW wavefronts runs the T-step forward of stream `b`.  `smem`: kCellSmem bytes of LDS.
-template <int NW>
+template <int NW, bool BF16 = false>
 __device__ __forceinline__ void cell_body(char* smem, const CellDev& cd, const float* __restrict__ x,
                                           const float* __restrict__ hx_in, float* __restrict__ out,
                                           float* __restrict__ hx_out, int T, int C, size_t b, int tid) {
@@ -201,13 +328,23 @@ __device__ __forceinline__ void cell_body(char* smem, const CellDev& cd, const f
         for (int i = tid; i < tt * F; i += kCellThreads) sx[i] = x[(b * T + t0) * F + i];
         __syncthreads();
         // ---- encoder, batched over the chunk (gruunet2.py:136-144)
-        mconv_down<NW, 1, kHidden, 2>(cd.w_down[0], cd.bt_down[0], sx, sd0, 8 * C, tt, wv, lane);
-        __syncthreads();
-        mconv_down<NW, kHidden, kHidden, 2>(cd.w_down[1], cd.bt_down[1], sd0, sd1, 4 * C, tt, wv, lane);
-        __syncthreads();
-        mconv_down<NW, kHidden, kHidden, 1>(cd.w_down[2], cd.bt_down[2], sd1, sd2, 2 * C, tt, wv, lane);
-        __syncthreads();
-        mconv_down<NW, kHidden, kGates, 1>(cd.w_down[3], cd.bt_down[3], sd2, sd3, C, tt, wv, lane);
+        if (BF16) {
+            mconv_down_bf16<NW, 1, kHidden, 2>(cd.wb_down[0], cd.bt_down[0], sx, sd0, 8 * C, tt, wv, lane);
+            __syncthreads();
+            mconv_down_bf16<NW, kHidden, kHidden, 2>(cd.wb_down[1], cd.bt_down[1], sd0, sd1, 4 * C, tt, wv, lane);
+            __syncthreads();
+            mconv_down_bf16<NW, kHidden, kHidden, 1>(cd.wb_down[2], cd.bt_down[2], sd1, sd2, 2 * C, tt, wv, lane);
+            __syncthreads();
+            mconv_down_bf16<NW, kHidden, kGates, 1>(cd.wb_down[3], cd.bt_down[3], sd2, sd3, C, tt, wv, lane);
+        } else {
+            mconv_down<NW, 1, kHidden, 2>(cd.w_down[0], cd.bt_down[0], sx, sd0, 8 * C, tt, wv, lane);
+            __syncthreads();
+            mconv_down<NW, kHidden, kHidden, 2>(cd.w_down[1], cd.bt_down[1], sd0, sd1, 4 * C, tt, wv, lane);
+            __syncthreads();
+            mconv_down<NW, kHidden, kHidden, 1>(cd.w_down[2], cd.bt_down[2], sd1, sd2, 2 * C, tt, wv, lane);
+            __syncthreads();
+            mconv_down<NW, kHidden, kGates, 1>(cd.w_down[3], cd.bt_down[3], sd2, sd3, C, tt, wv, lane);
+        }
         __syncthreads();
         // ---- recurrent part, sequential in t (gruunet2.py:232-240)
         for (int t = 0; t < tt; ++t) {
@@ -241,11 +378,19 @@ __device__ __forceinline__ void cell_body(char* smem, const CellDev& cd, const f
             __syncthreads();
         }
         // ---- decoder, batched over the chunk (gruunet2.py:184-199); skips are d2, d1, d0 (the last level has no cat)
-        mconv_up<NW, false, 1>(cd.w_up[0], cd.bt_up[0], shi, nullptr, su0, C, tt, wv, lane);
-        __syncthreads();
-        mconv_up<NW, true, 1>(cd.w_up[1], cd.bt_up[1], su0, sd2, su1, 2 * C, tt, wv, lane);
-        __syncthreads();
-        mconv_up<NW, true, 2>(cd.w_up[2], cd.bt_up[2], su1, sd1, su2, 4 * C, tt, wv, lane);
+        if (BF16) {
+            mconv_up_bf16<NW, false, 1>(cd.wb_up[0], cd.bt_up[0], shi, nullptr, su0, C, tt, wv, lane);
+            __syncthreads();
+            mconv_up_bf16<NW, true, 1>(cd.wb_up[1], cd.bt_up[1], su0, sd2, su1, 2 * C, tt, wv, lane);
+            __syncthreads();
+            mconv_up_bf16<NW, true, 2>(cd.wb_up[2], cd.bt_up[2], su1, sd1, su2, 4 * C, tt, wv, lane);
+        } else {
+            mconv_up<NW, false, 1>(cd.w_up[0], cd.bt_up[0], shi, nullptr, su0, C, tt, wv, lane);
+            __syncthreads();
+            mconv_up<NW, true, 1>(cd.w_up[1], cd.bt_up[1], su0, sd2, su1, 2 * C, tt, wv, lane);
+            __syncthreads();
+            mconv_up<NW, true, 2>(cd.w_up[2], cd.bt_up[2], su1, sd1, su2, 4 * C, tt, wv, lane);
+        }
         __syncthreads();
         // last level: one output channel; lane = (t, input position), weights through the scalar cache
         {

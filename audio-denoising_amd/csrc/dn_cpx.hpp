@@ -14,6 +14,9 @@
 #include <hip/hip_runtime.h>
 
 typedef float v2f __attribute__((ext_vector_type(2)));
+// operand fragment of v_mfma_f32_16x16x32_bf16: 8 bf16 (4 VGPRs); float -> bf16 is round-to-nearest-even (v_cvt_pk_bf16_f32)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ __bf16 f2bf(float x) { return (__bf16)x; }
 
 namespace dn {
 

@@ -53,6 +53,8 @@ struct HopArgs {
     float* ola; void* hop_out; int out_s16;
 };
 void launch_hop(const DspDev& d, const CellDev& c, const HopArgs& a, hipStream_t st);
+void launch_cell_bf16(const CellDev& c, const float* x, const float* hx_in, float* out, float* hx_out, int B, int T,
+                      int C, hipStream_t st);
 void launch_stream_shift(int n_fft, const float* hop_in, float* ring, int B, hipStream_t st);
 void launch_stream_ola(int n_fft, const float* y, float* ola, float* hop_out, int B, hipStream_t st);
 

@@ -32,6 +32,10 @@ struct CellDev {
     const float* w_down[4];  // data channels 1,17,17,17 -> 17,17,17,51
     const float* w_gh;       // [17][3][51]  (per-lane, pinned in VGPRs)
     const float* w_up[4];    // data channels 17,34,34,34 -> 17,17,17,1
+    // bf16 variants of the same fragments for v_mfma_f32_16x16x32_bf16 (BASELINE config 3): 8 bf16 per lane per k-step,
+    // K = 32 slots = channels 8 q + j of one tap (level 0: the 3 taps); [m-tile][k-step][64][8] / [m-tile][set][part][64][8]
+    const void* wb_down[4];
+    const void* wb_up[3];
     const float* bt_down[4]; // [Cout][Lout]    Lout = 8C,4C,2C,C
     const float* bt_gh;      // [51][C]
     const float* bt_up[4];   // [Cout][Lout]    Lout = 2C,4C,8C,16C

@@ -76,6 +76,9 @@ class GRUUNet2(nn.Module):
         self.latent_size = hidden_sizes[-1]
         self.num_compressed_bins = num_compressed_bins
         self.cell = _Cell(in_size, hidden_sizes, kernel_sizes, strides, paddings, num_gaussians)
+        # "fp32": exact-fp32 MFMA conv tiles (parity path).  "bf16": bf16 MFMA conv tiles, fp32 accumulate (BASELINE config 3;
+        # restated tolerance).  The reference itself cannot run below fp32 (dtype quirk).
+        self.conv_precision = "fp32"
         self._supported = (len(hidden_sizes) == 4 and all(h == _H for h in hidden_sizes) and
                            all(k == 3 for k in kernel_sizes) and all(s == 2 for s in strides) and
                            all(p == 1 for p in paddings) and num_gaussians == 6)
@@ -142,8 +145,10 @@ class GRUUNet2(nn.Module):
         h1 = torch.empty_like(h0)
         with torch.cuda.device(input.device):
             stream = torch.cuda.current_stream().cuda_stream
-            lib.check(lib.dn_cell_forward(handle, x.data_ptr(), h0.data_ptr(), out.data_ptr(), h1.data_ptr(),
-                                          B, T, F, Cb, C.c_void_p(stream)))
+            if self.conv_precision not in ("fp32", "bf16"):
+                raise ValueError("conv_precision must be 'fp32' or 'bf16'")
+            fwd = lib.dn_cell_forward if self.conv_precision == "fp32" else lib.dn_cell_forward_bf16
+            lib.check(fwd(handle, x.data_ptr(), h0.data_ptr(), out.data_ptr(), h1.data_ptr(), B, T, F, Cb, C.c_void_p(stream)))
         if two_dimmed:
             out = out.squeeze(0)
         return out, h1

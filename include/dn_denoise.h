@@ -89,6 +89,13 @@ void dn_model_destroy(dn_model* m);
 int dn_cell_forward(const dn_model* m, const float* x, const float* hx_in, float* out, float* hx_out,
                     int32_t B, int32_t T, int32_t F, int32_t C, void* stream);
 
+/* BASELINE config 3: the same forward with bf16 MFMA conv tiles (v_mfma_f32_16x16x32_bf16): encoder / decoder conv
+ * inputs and weights are rounded to bf16 (round to nearest even), accumulation, biases, the recurrent gate conv, the
+ * GRU math and the last decoder level stay fp32.  Not bit-compatible with the fp32 reference: tolerance is restated
+ * (tests/test_gpu_parity.py: <= 1e-2 relative RMS, <= 5e-1 max-abs on the mel residual; measured 4e-3 / 0.07-0.31). */
+int dn_cell_forward_bf16(const dn_model* m, const float* x, const float* hx_in, float* out, float* hx_out,
+                         int32_t B, int32_t T, int32_t F, int32_t C, void* stream);
+
 typedef struct dn_dsp_cfg {
     int32_t sample_rate;
     int32_t n_fft;   /* 1024 (hop = n_fft/2, win_length = n_fft) */

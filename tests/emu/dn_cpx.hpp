@@ -6,6 +6,22 @@
 
 typedef float v2f __attribute__((vector_size(8)));
 
+// bf16 operand fragments for the emulated v_mfma_f32_16x16x32_bf16
+struct dn_emu_bf16 {
+    uint16_t bits;
+    float to_float() const { uint32_t u = (uint32_t)bits << 16; float f; memcpy(&f, &u, 4); return f; }
+};
+inline dn_emu_bf16 f2bf(float x) {               // round to nearest even
+    uint32_t u; memcpy(&u, &x, 4);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return dn_emu_bf16{(uint16_t)(u >> 16)};
+}
+struct bf16x8 {
+    dn_emu_bf16 v[8];
+    dn_emu_bf16& operator[](int i) { return v[i]; }
+    const dn_emu_bf16& operator[](int i) const { return v[i]; }
+};
+
 namespace dn {
 inline v2f mk2(float re, float im) { return v2f{re, im}; }
 inline v2f cadd(v2f a, v2f b) { return a + b; }

@@ -157,3 +157,28 @@ inline f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, f32x4 c, int
     ctx.wave->wait();
     return d;
 }
+
+// v_mfma_f32_16x16x32_bf16: lane l supplies A[l & 15][8 (l >> 4) + j], B[8 (l >> 4) + j][l & 15], j = 0..7.
+// (bf16x8 comes from the dn_cpx.hpp stand-in; declared as a template so this header does not depend on it.)
+template <typename FRAG>
+inline f32x4 __builtin_amdgcn_mfma_f32_16x16x32_bf16(const FRAG& a, const FRAG& b, f32x4 c, int, int, int) {
+    using namespace dn_emu;
+    const int l = tIdx.x & 63;
+    static std::vector<std::vector<float>> pool(16, std::vector<float>(1024));   // [wave][A 16x32 | B 32x16]
+    float* s = pool[tIdx.x / 64].data();
+    for (int j = 0; j < 8; ++j) {
+        s[(l & 15) * 32 + 8 * (l >> 4) + j] = a[j].to_float();
+        s[512 + (8 * (l >> 4) + j) * 16 + (l & 15)] = b[j].to_float();
+    }
+    ctx.wave->wait();
+    const int col = l & 15, q = l >> 4;
+    f32x4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        const int row = q * 4 + r;
+        float acc = c[r];
+        for (int k = 0; k < 32; ++k) acc = std::fmaf(s[row * 32 + k], s[512 + k * 16 + col], acc);
+        d[r] = acc;
+    }
+    ctx.wave->wait();
+    return d;
+}

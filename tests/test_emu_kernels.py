@@ -288,3 +288,20 @@ def test_r1_process_frame_matches_oracle(lib, dsp_r1):
     assert np.abs(resid - g["predicted_diff"][:B]).max() <= 1e-4
     assert np.abs(hx - g["hx"][:B]).max() <= 1e-4
     assert np.sqrt(np.mean((out - g["out"][:B]) ** 2)) <= 1e-3
+
+
+@pytest.mark.parametrize("name", ["cell_dari_tult_B4_T3_F80.npz", "cell_dari_tult2_B4_T3_F64.npz"])
+def test_cell_bf16_conv_tiles_within_restated_tolerance(lib, name):
+    """BASELINE config 3 (bf16 MFMA conv tiles): tolerance restated -- <= 5e-1 max-abs, <= 1e-2 relative RMS (see tests/test_gpu_parity.py)."""
+    g = load_golden(name)
+    B, T, F = g["x"].shape
+    Cb = F // 16
+    m = make_model(lib, Cb, "dari_tult2" if "tult2" in name else "dari_tult")
+    out = np.zeros((B, T, F), np.float32)
+    hx1 = np.zeros((B, 17, Cb), np.float32)
+    lib.check(lib.dn_cell_forward_bf16(m, emu.ptr(emu.f32(g["x"])), emu.ptr(emu.f32(g["hx0"])), emu.ptr(out), emu.ptr(hx1), B, T, F, Cb, None))
+    lib.dn_model_destroy(m)
+    err = out - g["out"]
+    assert np.abs(err).max() <= 5e-1
+    assert np.sqrt(np.mean(err ** 2)) / np.sqrt(np.mean(g["out"] ** 2)) <= 1e-2
+    assert np.abs(err).max() > 1e-5            # it really is the reduced-precision path

@@ -429,3 +429,25 @@ def test_pipelined_hops_are_graph_capturable(dev):
     assert torch.equal(hx, hx_eager)
     for a, b in zip(eager, outs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("name", ["cell_dari_tult_B256_T3_F80.npz", "cell_dari_tult_B256_T3_F64.npz", "cell_dari_tult2_B3_T7_F80.npz"])
+def test_config3_bf16_mfma_conv_tiles_restated_tolerance(dev, name):
+    """BASELINE config 3: batch 256, GRUUNet2 with bf16 MFMA conv tiles (v_mfma_f32_16x16x32_bf16, fp32 accumulate).
+    Tolerance restated on the mel residual against the reference's fp32 golden: relative RMS <= 1e-2 and max-abs <= 5e-1
+    (outputs span +-6).  Measured on the MI355X (tools/bf16_error_probe.py): rel-RMS 3.7e-3 .. 4.2e-3 on every case --
+    the 2.9e-3 .. 4.4e-3 SURVEY.md 8d predicts for bf16-rounded conv inputs + weights -- and max-abs 0.07 .. 0.31 (the tail
+    of 49k outputs at batch 256 with random non-zero hx; 0.15 on the 20-hop chain that starts from hx = 0)."""
+    g = load_golden(name)
+    F = g["x"].shape[2]
+    m = _model(dev, F // 16, "dari_tult2" if "dari_tult2" in name else "dari_tult")
+    m.conv_precision = "bf16"
+    out, hx = m(torch.from_numpy(g["x"]).to(dev), torch.from_numpy(g["hx0"]).to(dev))
+    err = out.cpu().numpy() - g["out"]
+    assert np.abs(err).max() <= 5e-1
+    assert np.sqrt(np.mean(err ** 2)) / np.sqrt(np.mean(g["out"] ** 2)) <= 1e-2
+    assert np.abs(hx.cpu().numpy() - g["hx1"]).max() <= 5e-2
+    assert np.abs(err).max() > 1e-5                       # really the reduced-precision path
+    m.conv_precision = "fp32"
+    out32, _ = m(torch.from_numpy(g["x"]).to(dev), torch.from_numpy(g["hx0"]).to(dev))
+    assert np.abs(out32.cpu().numpy() - g["out"]).max() <= TOL_RESIDUAL
