@@ -11,6 +11,10 @@ import ctypes as C
 import os
 import threading
 
+# PyTorch must load ITS HIP runtime first: libdn_denoise.so then binds to the same libamdhip64 instance (same device
+# context, same streams).  Loaded the other way round, the process ends up with a runtime that sees no device.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdn_denoise.so")
 
