@@ -107,7 +107,6 @@ __device__ __forceinline__ void gl_body(char* smem, const DspDev& d, const float
     //   column 1: s[n]
     //   column 2: n < H -> s[n+H], else s[3H-2-n] (reflection)
     v2f wkh[kNP], wsyn[kNV], cw[kNV];
-    int src0[kNV], src1[kNV];
 #pragma unroll
     for (int t = 0; t < kNP; ++t) wkh[t] = cscale(reinterpret_cast<const v2f*>(d.twr)[lane + 64 * t], 0.5f);
 #pragma unroll
@@ -120,7 +119,6 @@ __device__ __forceinline__ void gl_body(char* smem, const DspDev& d, const float
         if (w == 1) { i0 = n0; i1 = n1; }
         else if (w == 0) { i0 = n0 < kHop ? kHop - n0 : n0 - kHop; i1 = n1 < kHop ? kHop - n1 : n1 - kHop; }
         else { i0 = n0 < kHop ? n0 + kHop : 3 * kHop - 2 - n0; i1 = n1 < kHop ? n1 + kHop : 3 * kHop - 2 - n1; }
-        src0[t] = i0; src1[t] = i1;
         cw[t] = mk2(ww[0] * d.inv_env[i0], ww[1] * d.inv_env[i1]);
     }
 
@@ -217,8 +215,16 @@ __device__ __forceinline__ void gl_body(char* smem, const DspDev& d, const float
         }
         // ---- stft of the rebuilt signal (centre, reflect): this wave's column, analysis window
 #pragma unroll
-        for (int t = 0; t < kNV; ++t)
-            v[t] = mk2(y1[src0[t]] + yo[src0[t]], y1[src1[t]] + yo[src1[t]]) * cw[t];
+        for (int t = 0; t < kNV; ++t) {
+            // source samples of (n0, n0+1), n0 = 2 (lane + 64 t): n0 < H exactly when t < NP, so the reflection case is
+            // known per t at compile time and every address is +-2*lane plus a constant
+            const int n0 = 2 * (lane + 64 * t);
+            int i0, i1;
+            if (W == 1) { i0 = n0; i1 = n0 + 1; }
+            else if (W == 0) { if (t < kNP) { i0 = kHop - n0; i1 = i0 - 1; } else { i0 = n0 - kHop; i1 = i0 + 1; } }
+            else { if (t < kNP) { i0 = n0 + kHop; i1 = i0 + 1; } else { i0 = 3 * kHop - 2 - n0; i1 = i0 - 1; } }
+            v[t] = mk2(y1[i0] + yo[i0], y1[i1] + yo[i1]) * cw[t];
+        }
         G::Fft::template run<false>(v, tw, mytile, lane);
         rfft_split_pairs<kNV>(v, wkh, lane, xlo, xhi, xmid);
         // ---- phase update with momentum
