@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libdn_denoise.so")
 
 # every symbol include/dn_denoise.h declares
 SYMBOLS = (
-    "dn_model_create", "dn_model_destroy", "dn_cell_forward", "dn_cell_forward_bf16", "dn_dsp_create", "dn_dsp_destroy",
+    "dn_model_create", "dn_model_destroy", "dn_cell_forward", "dn_cell_forward_ex", "dn_cell_forward_bf16", "dn_stft_general", "dn_server_rows", "dn_istft_general", "dn_dsp_create", "dn_dsp_destroy",
     "dn_dsp_get_tables", "dn_stft", "dn_stft_mel_log1p", "dn_mel_scale", "dn_invmel", "dn_residual_invmel",
     "dn_griffinlim", "dn_synthesis", "dn_istft", "dn_workspace_bytes", "dn_process_frame", "dn_stream_step",
     "dn_pipe_create", "dn_pipe_destroy", "dn_pipe_submit", "dn_pipe_flush", "dn_pipe_stream_create", "dn_pipe_stream_push",
@@ -66,6 +66,10 @@ class DnLib:
         L.dn_model_destroy.restype = None
         L.dn_cell_forward.argtypes = [vp, p, p, p, p, i32, i32, i32, i32, vp]
         L.dn_cell_forward_bf16.argtypes = [vp, p, p, p, p, i32, i32, i32, i32, vp]
+        L.dn_cell_forward_ex.argtypes = [vp, p, p, p, p, i32, i32, i32, i32, f32, vp]
+        L.dn_stft_general.argtypes = [vp, p, p, p, i32, i32, vp]
+        L.dn_server_rows.argtypes = [vp, p, p, p, p, i32, vp]
+        L.dn_istft_general.argtypes = [vp, p, p, i32, i32, vp]
         L.dn_dsp_create.argtypes = [C.POINTER(DspCfg), vp, vp, vp, C.POINTER(vp)]
         L.dn_dsp_destroy.argtypes = [vp]
         L.dn_dsp_destroy.restype = None

@@ -381,6 +381,20 @@ int dn_cell_forward(const dn_model* m, const float* x, const float* hx_in, float
     return check_launch("cell_kernel");
 }
 
+int dn_cell_forward_ex(const dn_model* m, const float* x, const float* hx_in, float* out, float* hx_out, int32_t B,
+                       int32_t T, int32_t F, int32_t C, float hx_out_scale, void* stream) {
+    if (B == 0) return DN_OK;
+    if (!m || !x || !out || !hx_out) return fail(DN_ERR_INVALID, "dn_cell_forward_ex: null argument");
+    if (B < 0 || T < 0) return fail(DN_ERR_INVALID, "dn_cell_forward_ex: negative size");
+    if (C < 1 || C > dn::kMaxC) return fail(DN_ERR_UNSUPPORTED, "compressed bins C must be in 1.." + std::to_string(dn::kMaxC));
+    if (F != 16 * C) return fail(DN_ERR_INVALID, "need F == 16*C");
+    BiasSet* bs = nullptr;
+    int rc = build_bias(const_cast<dn_model*>(m), C, &bs);
+    if (rc != DN_OK) return rc;
+    dn::launch_cell_ex(bs->view, x, hx_in, out, hx_out, B, T, C, hx_out_scale, as_stream(stream));
+    return check_launch("cell_kernel_ex");
+}
+
 int dn_cell_forward_bf16(const dn_model* m, const float* x, const float* hx_in, float* out, float* hx_out, int32_t B,
                          int32_t T, int32_t F, int32_t C, void* stream) {
     if (B == 0) return DN_OK;
@@ -593,6 +607,34 @@ int dn_istft(const dn_dsp* d, const float* spec, float* wave, int32_t B, void* s
 static size_t frame_scratch_bytes(const dn_dsp* d, int32_t B) {
     const size_t M = (size_t)d->cfg.n_mels, K = (size_t)d->cfg.n_fft / 2 + 1;
     return ((size_t)B * (6 * M + 3 * K + 1) * sizeof(float) + 255) & ~size_t(255);
+}
+
+int dn_stft_general(const dn_dsp* d, const float* x, float* spec, float* logmel, int32_t B, int32_t L, void* stream) {
+    if (B == 0) return DN_OK;
+    if (!d || !x || (!spec && !logmel)) return fail(DN_ERR_INVALID, "dn_stft_general: null argument");
+    if (B < 0) return fail(DN_ERR_INVALID, "dn_stft_general: negative batch");
+    if (L <= d->cfg.n_fft / 2) return fail(DN_ERR_INVALID, "dn_stft_general: reflect padding needs more than n_fft/2 samples (as torch.stft)");
+    if (logmel && d->cfg.n_mels <= 0) return fail(DN_ERR_INVALID, "plan was created without mel stages");
+    dn::launch_stft_general(d->view, x, spec, logmel, B, L, as_stream(stream));
+    return check_launch("stft_general_kernel");
+}
+
+int dn_server_rows(const dn_dsp* d, const float* logmel, const float* model_out, const float* spec_in, float* spec_out, int32_t rows,
+                   void* stream) {
+    if (rows == 0) return DN_OK;
+    if (!d || !logmel || !model_out || !spec_in || !spec_out) return fail(DN_ERR_INVALID, "dn_server_rows: null argument");
+    if (rows < 0) return fail(DN_ERR_INVALID, "dn_server_rows: negative size");
+    if (d->cfg.n_mels <= 0) return fail(DN_ERR_INVALID, "plan was created without mel stages");
+    dn::launch_server_rows(d->view, logmel, model_out, spec_in, spec_out, rows, as_stream(stream));
+    return check_launch("server_rows_kernel");
+}
+
+int dn_istft_general(const dn_dsp* d, const float* spec, float* wave, int32_t B, int32_t T, void* stream) {
+    if (B == 0) return DN_OK;
+    if (!d || !spec || !wave) return fail(DN_ERR_INVALID, "dn_istft_general: null argument");
+    if (B < 0 || T < 2) return fail(DN_ERR_INVALID, "dn_istft_general: need B >= 0 and at least 2 columns");
+    dn::launch_istft_general(d->view, spec, wave, B, T, as_stream(stream));
+    return check_launch("istft_general_kernel");
 }
 
 size_t dn_workspace_bytes(const dn_dsp* d, int32_t B) {

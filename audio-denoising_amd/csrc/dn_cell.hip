@@ -50,6 +50,18 @@ void launch_cell(const CellDev& c, const float* x, const float* hx_in, float* ou
     hipLaunchKernelGGL(cell_kernel, dim3(B), dim3(kCellWaves * 64), 0, st, c, x, hx_in, out, hx_out, T, C);
 }
 
+__global__ __launch_bounds__(kCellWaves * 64) void cell_kernel_ex(CellDev cd, const float* __restrict__ x,
+                                                                 const float* __restrict__ hx_in, float* __restrict__ out,
+                                                                 float* __restrict__ hx_out, int T, int C, float hx_scale) {
+    __shared__ __attribute__((aligned(16))) char smem[kCellSmem];
+    cell_body<kCellWaves>(smem, cd, x, hx_in, out, hx_out, T, C, blockIdx.x, threadIdx.x, hx_scale);
+}
+
+void launch_cell_ex(const CellDev& c, const float* x, const float* hx_in, float* out, float* hx_out, int B, int T,
+                    int C, float hx_scale, hipStream_t st) {
+    hipLaunchKernelGGL(cell_kernel_ex, dim3(B), dim3(kCellWaves * 64), 0, st, c, x, hx_in, out, hx_out, T, C, hx_scale);
+}
+
 void launch_cell_bf16(const CellDev& c, const float* x, const float* hx_in, float* out, float* hx_out, int B, int T,
                       int C, hipStream_t st) {
     hipLaunchKernelGGL(cell_kernel_bf16, dim3(B), dim3(kCellWaves * 64), 0, st, c, x, hx_in, out, hx_out, T, C);

@@ -289,7 +289,8 @@ constexpr int kCellSmem = 4 * kCellLdsFloats;      // 34,976 B
 template <int NW, bool BF16 = false>
 __device__ __forceinline__ void cell_body(char* smem, const CellDev& cd, const float* __restrict__ x,
                                           const float* __restrict__ hx_in, float* __restrict__ out,
-                                          float* __restrict__ hx_out, int T, int C, size_t b, int tid) {
+                                          float* __restrict__ hx_out, int T, int C, size_t b, int tid,
+                                          float hx_scale = 1.0f) {
     constexpr int kCellThreads = NW * 64;
     constexpr int kGateSlots = (kGates * kMaxC + kCellThreads - 1) / kCellThreads;   // gate items per thread
     float* lds = reinterpret_cast<float*>(smem);
@@ -416,7 +417,8 @@ __device__ __forceinline__ void cell_body(char* smem, const CellDev& cd, const f
         }
     }
     __syncthreads();
-    for (int i = tid; i < kHidden * C; i += kCellThreads) hx_out[b * kHidden * C + i] = sh[i];
+    // (hx_scale != 1: the server variant's `hx = hx * 0.9`, server.py:214)
+    for (int i = tid; i < kHidden * C; i += kCellThreads) hx_out[b * kHidden * C + i] = sh[i] * hx_scale;
 }
 
 }  // namespace dn

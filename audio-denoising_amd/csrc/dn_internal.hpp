@@ -55,6 +55,12 @@ struct HopArgs {
 void launch_hop(const DspDev& d, const CellDev& c, const HopArgs& a, hipStream_t st);
 void launch_cell_bf16(const CellDev& c, const float* x, const float* hx_in, float* out, float* hx_out, int B, int T,
                       int C, hipStream_t st);
+void launch_cell_ex(const CellDev& c, const float* x, const float* hx_in, float* out, float* hx_out, int B, int T,
+                    int C, float hx_scale, hipStream_t st);
+void launch_stft_general(const DspDev& d, const float* x, float* spec, float* logmel, int B, int L, hipStream_t st);
+void launch_server_rows(const DspDev& d, const float* logmel, const float* model_out, const float* spec_in, float* spec_out, int rows,
+                        hipStream_t st);
+void launch_istft_general(const DspDev& d, const float* spec, float* wave, int B, int T, hipStream_t st);
 void launch_stream_shift(int n_fft, const float* hop_in, float* ring, int B, hipStream_t st);
 void launch_stream_ola(int n_fft, const float* y, float* ola, float* hop_out, int B, hipStream_t st);
 

@@ -102,6 +102,50 @@ class Denoiser:
                                                  seed, stream_id0, self.n_iter, self.momentum, ws.data_ptr(), B, st))
 
 
+class ServerDenoiser:
+    """The request-loop body of the reference's socket server (server.py:199-217) for B mono chunks at once:
+    STFT -> mel -> log1p -> GRUUNet2 over all T columns -> relu(out)*3, hx*=0.9 -> inverse mel of exp(log_mel-out)-1
+    -> torch.polar with the NOISY phase -> ISTFT.  Chunks may have any length L > n_fft/2; the result has
+    hop*(L//hop) samples (InverseSpectrogram with length=None).  Four launches; no CPU fallback."""
+
+    def __init__(self, model: GRUUNet2, sample_rate: int = 48000, n_fft: int = 1024, hop_length: int = 512, n_mels: int = 64,
+                 hx_decay: float = 0.9, device=None):
+        self.device = torch.device(device if device is not None else next(model.parameters()).device)
+        if self.device.type != "cuda":
+            raise RuntimeError("ServerDenoiser needs a 'cuda' device; there is no CPU path in this package")
+        self.lib = _lib.get_lib()
+        self.model, self.hx_decay = model, float(hx_decay)
+        self.sample_rate, self.n_fft, self.hop, self.n_mels = sample_rate, n_fft, hop_length, n_mels
+        self.n_stft = n_fft // 2 + 1
+        fb = melscale_fbanks(self.n_stft, 0.0, float(sample_rate // 2), n_mels, sample_rate)        # server.py:175-176
+        self.plan = DspPlan(self.device, sample_rate, n_fft, hop_length, n_mels, fb=fb, window=torch.hann_window(n_fft))
+
+    def process(self, x: torch.Tensor, hx: torch.Tensor | None = None):
+        """x (B, L) float32 on the GPU, hx (B,17,C) or None -> (wave (B, hop*(L//hop)), hx_new)."""
+        if not x.is_cuda or x.device != self.device or x.dtype != torch.float32 or x.dim() != 2:
+            raise ValueError(f"x must be a float32 (B, L) tensor on {self.device}")
+        B, L = x.shape
+        T = 1 + L // self.hop
+        Cb = self.n_mels // 16
+        dev, lib, plan = self.device, self.lib, self.plan
+        x = x.contiguous()
+        spec = torch.empty(B, T, self.n_stft, 2, dtype=torch.float32, device=dev)
+        logmel = torch.empty(B, T, self.n_mels, dtype=torch.float32, device=dev)
+        out = torch.empty_like(logmel)
+        hx0 = torch.zeros(B, self.model.latent_size, Cb, dtype=torch.float32, device=dev) if hx is None else hx.contiguous()
+        hx1 = torch.empty_like(hx0)
+        wave = torch.empty(B, self.hop * (T - 1), dtype=torch.float32, device=dev)
+        model_h = self.model._native(dev)
+        with torch.cuda.device(dev):
+            st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            lib.check(lib.dn_stft_general(plan.handle, x.data_ptr(), spec.data_ptr(), logmel.data_ptr(), B, L, st))
+            lib.check(lib.dn_cell_forward_ex(model_h, logmel.data_ptr(), hx0.data_ptr(), out.data_ptr(), hx1.data_ptr(), B, T, self.n_mels, Cb,
+                                             self.hx_decay, st))
+            lib.check(lib.dn_server_rows(plan.handle, logmel.data_ptr(), out.data_ptr(), spec.data_ptr(), spec.data_ptr(), B * T, st))
+            lib.check(lib.dn_istft_general(plan.handle, spec.data_ptr(), wave.data_ptr(), B, T, st))
+        return wave, hx1
+
+
 class HopPipeline:
     """Software-pipelined hops (``dn_pipe_*``): one launch per hop carries hop n's Griffin-Lim workgroups next to
     hop n+1's analysis + GRUUNet2 + inverse-mel workgroups; ``hx`` is the only dependency between hops.

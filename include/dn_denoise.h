@@ -22,6 +22,7 @@
  *   dn_griffinlim                       app3.py:213-217  GriffinLim(power=1)(lin) (* peak)
  *   dn_synthesis                        app3.py:203-217  residual .. InverseMelScale .. GriffinLim (* peak), one launch
  *   dn_istft                            server.py:174,216 InverseSpectrogram
+ *   dn_stft_general / dn_server_rows / dn_istft_general / dn_cell_forward_ex   server.py:199-217  the socket server's variant
  *   dn_process_frame                    app3.py:178-217  the whole per-hop loop body for B streams
  *   dn_stream_step                      app3.py:178-226  the same plus ring buffer / overlap-add state (P12)
  *   dn_pipe_*                           app3.py:178-217  the same hop, consecutive hops software-pipelined in one launch per hop
@@ -89,6 +90,10 @@ void dn_model_destroy(dn_model* m);
 int dn_cell_forward(const dn_model* m, const float* x, const float* hx_in, float* out, float* hx_out,
                     int32_t B, int32_t T, int32_t F, int32_t C, void* stream);
 
+/* dn_cell_forward with the returned state scaled: hx_out = hx' * hx_out_scale (the `hx = hx * 0.9` of server.py:214). */
+int dn_cell_forward_ex(const dn_model* m, const float* x, const float* hx_in, float* out, float* hx_out,
+                       int32_t B, int32_t T, int32_t F, int32_t C, float hx_out_scale, void* stream);
+
 /* BASELINE config 3: the same forward with bf16 MFMA conv tiles (v_mfma_f32_16x16x32_bf16): encoder / decoder conv
  * inputs and weights are rounded to bf16 (round to nearest even), accumulation, biases, the recurrent gate conv, the
  * GRU math and the last decoder level stay fp32.  Not bit-compatible with the fp32 reference: tolerance is restated
@@ -153,6 +158,17 @@ int dn_synthesis(const dn_dsp* d, const float* x, const float* diff, const float
 
 /* torch.istft(center=True, length=None) of 3 columns: spec [dev][B][3][K] complex -> wave [dev][B][n_fft]. */
 int dn_istft(const dn_dsp* d, const float* spec, float* wave, int32_t B, void* stream);
+
+/* ---- Arbitrary-length chunks: the request loop of the reference's socket server (server.py:199-217) ----
+ * dn_stft_general: Spectrogram(power=None) of x [dev][B][L] (any L > n_fft/2) -> spec [dev][B][T][K] complex (may be NULL),
+ *   and/or logmel [dev][B][T][M] = log1p(MelScale(|spec|)) (may be NULL); T = 1 + L / hop.          server.py:207-210
+ * dn_server_rows: per (b,t) row: relu(model_out) * 3, exp(logmel - .) - 1, InverseMelScale, torch.polar(., angle(spec_in))
+ *   -> spec_out [dev][rows][K] complex (may alias spec_in).                                         server.py:213-216
+ * dn_istft_general: InverseSpectrogram (length=None), spec [dev][B][T][K], T >= 2 -> wave [dev][B][hop*(T-1)].  server.py:216 */
+int dn_stft_general(const dn_dsp* d, const float* x, float* spec, float* logmel, int32_t B, int32_t L, void* stream);
+int dn_server_rows(const dn_dsp* d, const float* logmel, const float* model_out, const float* spec_in, float* spec_out,
+                   int32_t rows, void* stream);
+int dn_istft_general(const dn_dsp* d, const float* spec, float* wave, int32_t B, int32_t T, void* stream);
 
 /* Scratch the fused entry points need, in bytes, for a batch of B streams. */
 size_t dn_workspace_bytes(const dn_dsp* d, int32_t B);

@@ -184,6 +184,22 @@ def main():
         y = st.push(sig, init_angles_per_hop=inits)
     np.savez(os.path.join(GOLD, "stream_R1.npz"), signal=sig.numpy(), init_angles=torch.stack(inits).numpy(),
              out=y.numpy(), ola=st.ola.numpy(), hx=st.hx.numpy())
+    # server.py request loop (R2 parameters, checkpoint GRUUNet2-good): 3 consecutive chunks of 9 hops, 2 streams
+    from oracle import server_ref
+    p = pipeline_ref.PARAMS_R2
+    g = torch.Generator().manual_seed(515)
+    chunks = 0.1 * torch.randn(3, 2, 9 * p.hop, generator=g)
+    sd = model_ref.unflatten_weights(np.fromfile(os.path.join(GOLD, "weights_good.bin"), dtype=np.float32))
+    hx, outs = None, []
+    with torch.no_grad():
+        for c in range(3):
+            r = server_ref.process_chunk(sd, chunks[c], hx, p)
+            hx = r["hx"]
+            outs.append(r["out"])
+            if c == 0:
+                first = r
+    np.savez(os.path.join(GOLD, "server_R2.npz"), chunks=chunks.numpy(), out=torch.stack(outs).numpy(), hx=hx.numpy(),
+             log_mel0=first["log_mel"].numpy(), model_out0=first["model_out"].numpy(), lin0=first["lin"].numpy(), spec0=first["spec"].numpy())
     print("fixtures written to", GOLD)
     for fn in sorted(os.listdir(GOLD)):
         print(f"  {fn:45s} {os.path.getsize(os.path.join(GOLD, fn)):>9d} B")

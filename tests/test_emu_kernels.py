@@ -305,3 +305,35 @@ def test_cell_bf16_conv_tiles_within_restated_tolerance(lib, name):
     assert np.abs(err).max() <= 5e-1
     assert np.sqrt(np.mean(err ** 2)) / np.sqrt(np.mean(g["out"] ** 2)) <= 1e-2
     assert np.abs(err).max() > 1e-5            # it really is the reduced-precision path
+
+
+def test_server_variant_matches_oracle(lib):
+    """server.py:199-217 (R2 parameters, checkpoint GRUUNet2-good): general-length STFT, model over T columns with
+    hx*0.9, relu*3 / exp-1 / inverse mel / polar with the noisy phase, general-length ISTFT."""
+    from oracle import pipeline_ref
+    p = pipeline_ref.PARAMS_R2
+    g = load_golden("server_R2.npz")
+    fb = dsp_ref.melscale_fbanks(p.n_stft, p.n_mels, p.sample_rate).numpy()
+    d = C.c_void_p()
+    lib.check(lib.dn_dsp_create(C.byref(DspCfg(p.sample_rate, p.n_fft, p.hop, p.n_mels)), emu.ptr(emu.f32(fb)), None,
+                                emu.ptr(emu.f32(torch.hann_window(p.n_fft).numpy())), C.byref(d)))
+    m = make_model(lib, 4, "good")
+    B, L = g["chunks"].shape[1:]
+    T = 1 + L // p.hop
+    hx = np.zeros((B, 17, 4), np.float32)
+    for c in range(2):
+        x = emu.f32(g["chunks"][c])
+        spec = np.zeros((B, T, p.n_stft, 2), np.float32)
+        logmel = np.zeros((B, T, p.n_mels), np.float32)
+        out = np.zeros_like(logmel)
+        wave = np.zeros((B, p.hop * (T - 1)), np.float32)
+        lib.check(lib.dn_stft_general(d, emu.ptr(x), emu.ptr(spec), emu.ptr(logmel), B, L, None))
+        lib.check(lib.dn_cell_forward_ex(m, emu.ptr(logmel), emu.ptr(hx), emu.ptr(out), emu.ptr(hx), B, T, p.n_mels, 4, 0.9, None))
+        if c == 0:
+            assert np.abs(logmel - g["log_mel0"].transpose(0, 2, 1)).max() <= 2e-5
+            assert np.abs(out - g["model_out0"]).max() <= 1e-4
+        lib.check(lib.dn_server_rows(d, emu.ptr(logmel), emu.ptr(out), emu.ptr(spec), emu.ptr(spec), B * T, None))
+        lib.check(lib.dn_istft_general(d, emu.ptr(spec), emu.ptr(wave), B, T, None))
+        assert np.sqrt(np.mean((wave - g["out"][c]) ** 2)) <= 1e-3 * max(1.0, np.sqrt(np.mean(g["out"][c] ** 2)))
+    lib.dn_model_destroy(m)
+    lib.dn_dsp_destroy(d)

@@ -451,3 +451,25 @@ def test_config3_bf16_mfma_conv_tiles_restated_tolerance(dev, name):
     m.conv_precision = "fp32"
     out32, _ = m(torch.from_numpy(g["x"]).to(dev), torch.from_numpy(g["hx0"]).to(dev))
     assert np.abs(out32.cpu().numpy() - g["out"]).max() <= TOL_RESIDUAL
+
+
+def test_server_variant_matches_oracle_golden(dev):
+    """The socket server's request loop (server.py:199-217): R2 parameters, checkpoint GRUUNet2-good, three consecutive
+    chunks with hx carried (and decayed by 0.9), resynthesis with the noisy phase."""
+    from audio_denoising_amd.pipeline import ServerDenoiser
+    g = load_golden("server_R2.npz")
+    p = _params("R2")
+    sd = ServerDenoiser(_model(dev, 4, "good"), p.sample_rate, p.n_fft, p.hop, p.n_mels)
+    hx = None
+    for c in range(3):
+        wave, hx = sd.process(torch.from_numpy(g["chunks"][c]).to(dev), hx)
+        assert wave.shape == g["out"][c].shape
+        assert np.sqrt(np.mean((wave.cpu().numpy() - g["out"][c]) ** 2)) <= TOL_WAVE_RMS
+    assert np.abs(hx.cpu().numpy() - g["hx"]).max() <= 5e-4
+    # ragged: a chunk that is not a multiple of the hop (the client of server.py sends e.g. 4800 samples)
+    x = torch.randn(2, 4800, generator=torch.Generator().manual_seed(2)).to(dev) * 0.1
+    w, _ = sd.process(x, None)
+    assert w.shape == (2, p.hop * (4800 // p.hop)) and torch.isfinite(w).all()
+    from oracle import model_ref, server_ref
+    ref = server_ref.process_chunk(_state_dict("good"), x.cpu(), None, p)
+    assert (w.cpu() - ref["out"]).pow(2).mean().sqrt().item() <= TOL_WAVE_RMS
