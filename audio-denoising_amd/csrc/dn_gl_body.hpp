@@ -142,12 +142,13 @@ __device__ __forceinline__ void gl_body(char* smem, const DspDev& d, const float
         pmid = mk2(0.0f, 0.0f);
     }
 
-    // a = rebuilt - m * tprev; tprev = rebuilt; angles = a / (|a| + 1e-16)   (v_sqrt / v_rcp: 1 ulp)
-    auto update = [mom](v2f reb, v2f& prev, v2f& ang) {
+    // a = rebuilt - m * tprev; tprev = rebuilt; angles = a / (|a| + 1e-16)   (v_sqrt / v_rcp: 1 ulp).
+    // The state keeps X = angles * magnitude (what the next istft consumes) instead of the angles themselves.
+    auto update = [mom](v2f reb, v2f& prev, v2f& x, float m) {
         const v2f a = reb - prev * mom;
         prev = reb;
         const float inv = __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(fmaf(a[0], a[0], a[1] * a[1])) + 1e-16f);
-        ang = a * inv;
+        x = a * (inv * m);
     };
 
     if (FROM_MEL) __syncthreads();        // the prologue scratch becomes the overlap-add lines
@@ -156,15 +157,15 @@ __device__ __forceinline__ void gl_body(char* smem, const DspDev& d, const float
     // stores and every other column-dependent choice become straight-line code instead of per-value predicates.
     auto iterate = [&](auto wc) {
     constexpr int W = decltype(wc)::value;
-    v2f v[kNV], xlo[kNP], xhi[kNP], xmid;
-    for (int it = 0;; ++it) {
-        // ---- istft of angles * magnitude: Hermitian merge, inverse FFT, synthesis window, overlap-add lines
+    v2f v[kNV], xlo[kNP], xhi[kNP], xmid, rlo[kNP], rhi[kNP], rmid;
 #pragma unroll
-        for (int t = 0; t < kNP; ++t) {
-            xlo[t] = alo[t] * mlo[t];
-            xhi[t] = ahi[t] * mhi[t];
-        }
-        xmid = amid * mmid;
+    for (int t = 0; t < kNP; ++t) {
+        xlo[t] = alo[t] * mlo[t];
+        xhi[t] = ahi[t] * mhi[t];
+    }
+    xmid = amid * mmid;
+    for (int it = 0;; ++it) {
+        // ---- istft of X = angles * magnitude: Hermitian merge, inverse FFT, synthesis window, overlap-add lines
         irfft_merge_pairs<kNV>(xlo, xhi, xmid, wkh, lane, v);
         G::Fft::template run<true>(v, tw, mytile, lane);
         float* y1 = ybuf[it & 1][0];
@@ -226,14 +227,14 @@ __device__ __forceinline__ void gl_body(char* smem, const DspDev& d, const float
             v[t] = mk2(y1[i0] + yo[i0], y1[i1] + yo[i1]) * cw[t];
         }
         G::Fft::template run<false>(v, tw, mytile, lane);
-        rfft_split_pairs<kNV>(v, wkh, lane, xlo, xhi, xmid);
+        rfft_split_pairs<kNV>(v, wkh, lane, rlo, rhi, rmid);
         // ---- phase update with momentum
 #pragma unroll
         for (int t = 0; t < kNP; ++t) {
-            update(xlo[t], plo[t], alo[t]);
-            update(xhi[t], phi[t], ahi[t]);
+            update(rlo[t], plo[t], xlo[t], mlo[t]);
+            update(rhi[t], phi[t], xhi[t], mhi[t]);
         }
-        update(xmid, pmid, amid);
+        update(rmid, pmid, xmid, mmid);
     }
     };
     if (w == 0) iterate(std::integral_constant<int, 0>{});
