@@ -147,6 +147,21 @@ def side_measurement(args, dn, B, dev):
         def step(i):
             ps.push(hop)
         fin = ps.flush
+    elif args.pcie:
+        # the boundary hands over HOST buffers: every hop moves its frames up and its result down over PCIe (pinned,
+        # async on the same stream; double-buffered so hop n's result copy does not wait for its Griffin-Lim early)
+        host_in = (0.1 * torch.randn(B, dn.n_fft, generator=g)).pin_memory()
+        host_out = [torch.empty(B, dn.n_fft).pin_memory() for _ in range(2)]
+        dframes = [torch.empty(B, dn.n_fft, device=dev) for _ in range(2)]
+        douts = [torch.empty(B, dn.n_fft, device=dev) for _ in range(2)]
+        pipe = HopPipeline(dn, B)
+
+        def step(i):
+            s = i & 1
+            dframes[s].copy_(host_in, non_blocking=True)
+            pipe.submit(dframes[s], hx, douts[s], seed=1000 + i)          # also completes hop i-1 (its Griffin-Lim blocks)
+            host_out[s ^ 1].copy_(douts[s ^ 1], non_blocking=True)
+        fin = pipe.flush
     else:
         frames = (0.1 * torch.randn(B, dn.n_fft, generator=g)).to(dev)
         pipe = HopPipeline(dn, B)
@@ -168,7 +183,7 @@ def side_measurement(args, dn, B, dev):
     fin()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    print(json.dumps({"metric": "frames/s (side measurement, not the headline)", "preset": args.preset, "mode": "stream" if args.stream else "frames",
+    print(json.dumps({"metric": "frames/s (side measurement, not the headline)", "preset": args.preset, "mode": "stream" if args.stream else ("frames+pcie" if args.pcie else "frames"),
                       "value": round(B * args.steps / el, 1), "unit": "frames/s", "streams": B, "ms_per_step": round(1e3 * el / args.steps, 4),
                       "n_fft": dn.n_fft, "hop": dn.hop, "n_mels": dn.n_mels, "sample_rate": dn.sample_rate,
                       "realtime_streams_per_gpu": int(B * args.steps / el / (dn.sample_rate / dn.hop))}), flush=True)
@@ -183,6 +198,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial", action="store_true", help="one hop at a time, 3 launches (dn_process_frame) instead of the software-pipelined hop")
     ap.add_argument("--preset", choices=sorted(PRESETS), default="S", help="S = the metric's config; R1/R2 = the reference's own parameters (extra measurements)")
+    ap.add_argument("--pcie", action="store_true", help="side measurement: frames arrive in pinned host memory and results return to it every hop")
     ap.add_argument("--stream", action="store_true", help="streaming mode (BASELINE config 5): pipe-owned ring/overlap-add/hx state, one hop of new samples per step")
     args = ap.parse_args()
 
@@ -207,7 +223,7 @@ def main():
     from audio_denoising_amd.shard import shard_range
     dn = build_denoiser(dev, args.preset)
     B = args.batch
-    if args.preset != "S" or args.stream:
+    if args.preset != "S" or args.stream or args.pcie:
         return side_measurement(args, dn, B, dev)
     lo, hi = shard_range(B * world, world, rank)          # this rank's global stream ids
     g = torch.Generator().manual_seed(1234 + rank)
