@@ -11,7 +11,8 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(REPO, "audio-denoising_amd", "csrc")
-OUT = os.path.join(HERE, "build", "libdn_emu.so")
+ASAN = os.environ.get("DN_EMU_ASAN") == "1"      # AddressSanitizer build of the host emulation (run pytest under LD_PRELOAD=libasan)
+OUT = os.path.join(HERE, "build", "libdn_emu_asan.so" if ASAN else "libdn_emu.so")
 sys.path.insert(0, REPO)
 
 
@@ -22,7 +23,8 @@ def build(force=False):
     if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= max(os.path.getmtime(d) for d in deps):
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    cmd = ["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-pthread", "-x", "c++", "-I", HERE] + srcs + ["-o", OUT]
+    opt = ["-O1", "-g", "-fsanitize=address", "-fno-omit-frame-pointer"] if ASAN else ["-O2"]
+    cmd = ["g++", "-std=c++17"] + opt + ["-fPIC", "-shared", "-pthread", "-x", "c++", "-I", HERE] + srcs + ["-o", OUT]
     subprocess.run(cmd, check=True)
     return OUT
 
