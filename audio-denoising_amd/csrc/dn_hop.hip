@@ -30,6 +30,9 @@ __global__ __launch_bounds__(kHopThreads) void hop_kernel(DspDev d, CellDev cd, 
     __shared__ __attribute__((aligned(16))) char smem[hop_smem<NFFT>()];
     const int tid = threadIdx.x;
     if ((int)blockIdx.x < a.back_B) {
+        // the Griffin-Lim chain is the critical path of the launch: let its waves win issue arbitration against the
+        // front-half waves they share SIMDs with
+        __builtin_amdgcn_s_setprio(3);
         if (a.ola == nullptr)
             gl_body<NFFT, false, false>(smem, d, a.gl_lin, nullptr, reinterpret_cast<const v2f*>(a.gl_init), a.gl_seed, a.gl_sid0,
                                         a.gl_peak, a.gl_out, a.n_iter, a.mom, blockIdx.x, tid);

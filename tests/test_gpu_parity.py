@@ -473,3 +473,33 @@ def test_server_variant_matches_oracle_golden(dev):
     from oracle import model_ref, server_ref
     ref = server_ref.process_chunk(_state_dict("good"), x.cpu(), None, p)
     assert (w.cpu() - ref["out"]).pow(2).mean().sqrt().item() <= TOL_WAVE_RMS
+
+
+def test_maximum_batch_streams_are_independent(dev):
+    """BASELINE config 5's total (8192 streams) on ONE GPU: every stream's result must equal what it gets in a small
+    batch (streams are independent; the device RNG is keyed by global stream id) -- checked on a spread of streams."""
+    from audio_denoising_amd.pipeline import Denoiser, HopPipeline
+    p = _params("S")
+    dn = Denoiser(_model(dev, 5), p.sample_rate, p.n_fft, p.hop, p.n_mels)
+    B = 8192
+    gen = torch.Generator().manual_seed(23)
+    frames = [(0.1 * torch.randn(B, p.n_fft, generator=gen)).to(dev) for _ in range(2)]
+    outs = [torch.empty(B, p.n_fft, device=dev) for _ in range(2)]
+    hx = dn.init_hx(B)
+    pipe = HopPipeline(dn, B)
+    for i in range(2):
+        pipe.submit(frames[i], hx, outs[i], seed=9 + i, stream_id0=0)
+    pipe.flush()
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(o).all() for o in outs)
+    for lo in (0, 4096, 8192 - 64):                      # three 64-stream slices, re-run alone with their global ids
+        hx_s = dn.init_hx(64)
+        small = [torch.empty(64, p.n_fft, device=dev) for _ in range(2)]
+        ps = HopPipeline(dn, 64)
+        for i in range(2):
+            ps.submit(frames[i][lo:lo + 64].contiguous(), hx_s, small[i], seed=9 + i, stream_id0=lo)
+        ps.flush()
+        torch.cuda.synchronize()
+        for i in range(2):
+            assert torch.equal(small[i], outs[i][lo:lo + 64])
+        assert torch.equal(hx_s, hx[lo:lo + 64])
