@@ -24,8 +24,11 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 template <int NFFT> constexpr int hop_smem() { return cmax(cmax(kCellSmem, gl_smem<NFFT>()), cmax(stft_smem<NFFT>(), kInvSmem)); }
 static_assert(kHopThreads == kGlThreads && kHopThreads == kStftThreads && kHopThreads == kInvThreads, "one block size for all bodies");
 
+// n_fft 1536: the Griffin-Lim body would take 330 registers and shut the front workgroup out of the CU; capping the
+// kernel at two waves per SIMD (256 registers, ~80 values spilled to scratch) keeps both halves resident (+30 % at 1024
+// streams).  n_fft 1024 fits in 229 registers without a cap (capping it costs 8 %).
 template <int NFFT>
-__global__ __launch_bounds__(kHopThreads) void hop_kernel(DspDev d, CellDev cd, HopArgs a) {
+__global__ __launch_bounds__(kHopThreads, NFFT == 1536 ? 2 : 1) void hop_kernel(DspDev d, CellDev cd, HopArgs a) {
     constexpr int kNR = NFFT;
     __shared__ __attribute__((aligned(16))) char smem[hop_smem<NFFT>()];
     const int tid = threadIdx.x;
