@@ -229,9 +229,9 @@ def test_process_frame_full_batch_vs_oracle_sample_and_shard_invariance(dev):
     assert torch.isfinite(whole).all()
 
 
-def test_two_stream_hop_pipeline_equals_serial_hops_bit_for_bit(dev):
-    """dn_pipe_* overlaps hop n's synthesis with hop n+1's analysis+model on two streams; the results (8 chained
-    hops, batch 256, device RNG) must equal the serial dn_process_frame sequence exactly."""
+def test_pipelined_hops_equal_serial_hops_bit_for_bit(dev):
+    """dn_pipe_* runs hop n's Griffin-Lim blocks next to hop n+1's analysis+model blocks in one launch per hop; the
+    results (8 chained hops, batch 256, device RNG) must equal the serial dn_process_frame sequence exactly."""
     from audio_denoising_amd.pipeline import Denoiser, HopPipeline
     from oracle import pipeline_ref
     p = pipeline_ref.PARAMS_S
