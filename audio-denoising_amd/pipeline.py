@@ -97,9 +97,10 @@ class Denoiser:
         B = frames.shape[0]
         ws = self._workspace(B)
         model_h = self.model._native(self.device)
-        st = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        self.lib.check(self.lib.dn_process_frame(model_h, self.plan.handle, frames.data_ptr(), hx.data_ptr(), out.data_ptr(), None, None,
-                                                 seed, stream_id0, self.n_iter, self.momentum, ws.data_ptr(), B, st))
+        with torch.cuda.device(self.device):          # the launch goes to the CURRENT device: make it the denoiser's
+            st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            self.lib.check(self.lib.dn_process_frame(model_h, self.plan.handle, frames.data_ptr(), hx.data_ptr(), out.data_ptr(), None, None,
+                                                     seed, stream_id0, self.n_iter, self.momentum, ws.data_ptr(), B, st))
 
 
 class ServerDenoiser:
@@ -170,13 +171,15 @@ class HopPipeline:
         d = self.dn
         keep, ia_ptr = d._angles_ptr(init_angles, self.batch)
         self._keep = (self._keep[1], keep)      # this hop's and the previous hop's phases stay alive
-        st = C.c_void_p(torch.cuda.current_stream(d.device).cuda_stream)
-        self.lib.check(self.lib.dn_pipe_submit(self.handle, frames.data_ptr(), hx.data_ptr(), out.data_ptr(), ia_ptr, seed, stream_id0,
-                                               d.n_iter, d.momentum, st))
+        with torch.cuda.device(d.device):
+            st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            self.lib.check(self.lib.dn_pipe_submit(self.handle, frames.data_ptr(), hx.data_ptr(), out.data_ptr(), ia_ptr, seed, stream_id0,
+                                                   d.n_iter, d.momentum, st))
 
     def flush(self) -> None:
-        st = C.c_void_p(torch.cuda.current_stream(self.dn.device).cuda_stream)
-        self.lib.check(self.lib.dn_pipe_flush(self.handle, st))
+        with torch.cuda.device(self.dn.device):
+            st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            self.lib.check(self.lib.dn_pipe_flush(self.handle, st))
 
 
 class PipelinedStream:
@@ -231,8 +234,9 @@ class PipelinedStream:
         ring = torch.empty(self.batch, d.n_fft, dtype=torch.float32, device=d.device)
         ola = torch.empty_like(ring)
         hx = torch.empty(self.batch, d.model.latent_size, d.num_compressed_bins, dtype=torch.float32, device=d.device)
-        st = C.c_void_p(torch.cuda.current_stream(d.device).cuda_stream)
-        self.lib.check(self.lib.dn_pipe_stream_get_state(self.handle, ring.data_ptr(), ola.data_ptr(), hx.data_ptr(), st))
+        with torch.cuda.device(d.device):
+            st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            self.lib.check(self.lib.dn_pipe_stream_get_state(self.handle, ring.data_ptr(), ola.data_ptr(), hx.data_ptr(), st))
         return ring, ola, hx
 
     def load_state(self, ring: torch.Tensor, ola: torch.Tensor, hx: torch.Tensor) -> None:
@@ -240,8 +244,9 @@ class PipelinedStream:
         for t in (ring, ola, hx):
             if t.device != self.dn.device or t.dtype != torch.float32 or not t.is_contiguous():
                 raise ValueError("state tensors must be contiguous float32 on the denoiser's device")
-        st = C.c_void_p(torch.cuda.current_stream(self.dn.device).cuda_stream)
-        self.lib.check(self.lib.dn_pipe_stream_set_state(self.handle, ring.data_ptr(), ola.data_ptr(), hx.data_ptr(), st))
+        with torch.cuda.device(self.dn.device):
+            st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            self.lib.check(self.lib.dn_pipe_stream_set_state(self.handle, ring.data_ptr(), ola.data_ptr(), hx.data_ptr(), st))
         self.pushes = max(self.pushes, self.dn.n_fft // self.dn.hop - 1)
 
 
