@@ -327,6 +327,10 @@ def main():
                          "launch_ms": round(dom_ms, 4),
                          "hbm_frac": round(dom_bytes * B / gl_s / 1e9 / PEAK_HBM_GBS, 6)},
             "kernel_ms": {k: round(v, 4) for k, v in kt.items()},
+            # MFMA utilisation of the UNet convs: conv FLOPs / (serial cell_kernel time x fp32 MFMA peak)
+            "conv_mfma": {"kernel": "cell_kernel (fp32 v_mfma_f32_16x16x4_f32)", "achieved": round(939150 * B / (kt["cell"] * 1e-3) / 1e12, 3),
+                          "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(939150 * B / (kt["cell"] * 1e-3) / 1e12 / PEAK_FP32_TFLOPS, 4),
+                          "note": "0.24 GFLOP per batch-256 launch is 1.5 us at peak: structurally latency-bound (SURVEY section 7)"},
             "schedule": "serial, 3 launches per hop (dn_process_frame)" if pipe is None else "software-pipelined, 1 launch per hop (dn_pipe_submit)",
             "serial_ms_per_step": round(serial_ms, 4),
             "whole_path": {"tflops": round(TOTAL_FLOP_PER_FRAME * value / 1e12, 3),
