@@ -503,3 +503,40 @@ def test_maximum_batch_streams_are_independent(dev):
         for i in range(2):
             assert torch.equal(small[i], outs[i][lo:lo + 64])
         assert torch.equal(hx_s, hx[lo:lo + 64])
+
+
+@pytest.mark.parametrize("tag", ["S", "R1"])
+def test_special_signals_match_oracle(dev, tag):
+    """Edge-case frames through the whole hop vs the oracle: impulses at the frame edges and centre, DC, the Nyquist
+    alternation, a bin-centred sine, sub-threshold and very large amplitudes, exact silence (app3.py:181-186 branches)."""
+    from audio_denoising_amd.pipeline import Denoiser
+    from oracle import dsp_ref, pipeline_ref
+    p = _params(tag)
+    N = p.n_fft
+    n = torch.arange(N, dtype=torch.float32)
+    frames = torch.zeros(10, N)
+    frames[0, 0] = 1.0
+    frames[1, N - 1] = -0.5
+    frames[2, N // 2] = 0.25
+    frames[3] = 0.3                                            # DC
+    frames[4] = 0.2 * (1 - 2 * (n % 2))                        # Nyquist alternation
+    frames[5] = 0.7 * torch.sin(2 * torch.pi * 37 * n / N)     # bin-centred tone
+    frames[6] = 5e-7 * torch.sin(2 * torch.pi * 5 * n / N)     # below the 1e-6 peak threshold: not normalised
+    frames[7] = 1e4 * torch.randn(N, generator=torch.Generator().manual_seed(1))
+    frames[8] = 0.0                                            # silence
+    frames[9] = 2e-6 * torch.randn(N, generator=torch.Generator().manual_seed(2))   # just above the threshold
+    C = p.num_compressed_bins
+    short = "dari_tult2" if tag == "R1" else "dari_tult"
+    dn = Denoiser(_model(dev, C, short), p.sample_rate, p.n_fft, p.hop, p.n_mels)
+    init = torch.rand(10, p.n_stft, 3, dtype=torch.complex64, generator=torch.Generator().manual_seed(4321))
+    out, hx, resid = dn.process_frame(frames.to(dev), None, init_angles=init.to(dev), return_residual=True)
+    fb = dsp_ref.melscale_fbanks(p.n_stft, p.n_mels, p.sample_rate)
+    with torch.no_grad():
+        ref = pipeline_ref.process_frame(_state_dict(short), frames, torch.zeros(10, 17, C), p, fb, init_angles=init)
+    assert torch.isfinite(out).all()
+    assert (resid.cpu() - ref["predicted_diff"]).abs().max().item() <= TOL_RESIDUAL
+    assert (hx.cpu() - ref["hx"]).abs().max().item() <= TOL_RESIDUAL
+    # waveform: per-frame RMS error relative to that frame's scale (outputs are multiplied back by the frame's peak)
+    scale = torch.maximum(ref["peak"], torch.tensor(1.0))
+    err = ((out.cpu() - ref["out"]) / scale[:, None]).pow(2).mean(1).sqrt()
+    assert err.max().item() <= TOL_WAVE_RMS, err
