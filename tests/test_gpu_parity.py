@@ -540,3 +540,38 @@ def test_special_signals_match_oracle(dev, tag):
     scale = torch.maximum(ref["peak"], torch.tensor(1.0))
     err = ((out.cpu() - ref["out"]) / scale[:, None]).pow(2).mean(1).sqrt()
     assert err.max().item() <= TOL_WAVE_RMS, err
+
+
+def test_c_abi_host_without_python_gives_the_same_samples(dev, tmp_path):
+    """examples/denoise_hop.cpp drives the path through include/dn_denoise.h only (no Python, no torch): built here with
+    hipcc, run as a child process, its output must equal the Python host's bit for bit (same seeds, device RNG)."""
+    import math
+    import shutil
+    import subprocess
+    from audio_denoising_amd import _lib
+    from audio_denoising_amd.pipeline import Denoiser
+    from conftest import REPO
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe, outf = str(tmp_path / "denoise_hop"), str(tmp_path / "out.f32")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.run([hipcc, "-O2", os.path.join(REPO, "examples", "denoise_hop.cpp"), "-I", os.path.join(REPO, "include"), "-L", libdir,
+                    "-ldn_denoise", f"-Wl,-rpath,{libdir}", "-o", exe], check=True)
+    B, hops = 4, 3
+    r = subprocess.run([exe, os.path.join(GOLDEN, "weights_dari_tult.bin"), outf, str(B), str(hops)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = np.fromfile(outf, dtype=np.float32).reshape(B, 1024)
+    # the same thing through the Python host with the library's NATIVE tables (fb/window NULL) to match the C program
+    p = _params("S")
+    dn = Denoiser(_model(dev, 5), p.sample_rate, p.n_fft, p.hop, p.n_mels)
+    from audio_denoising_amd.transforms import DspPlan
+    dn.plan = DspPlan(dev, p.sample_rate, p.n_fft, p.hop, p.n_mels)          # native HTK filterbank / Hann
+    hx = dn.init_hx(B)
+    out = torch.empty(B, 1024, device=dev)
+    for hop in range(hops):
+        h = np.zeros((B, 1024), np.float32)
+        for b in range(B):
+            t = (hop * 512 + np.arange(1024)) / 16000.0
+            h[b] = (0.3 * np.sin(2 * math.pi * (220.0 + 110.0 * b) * t) + 0.05 * np.sin(2 * math.pi * 3300.0 * t + b)).astype(np.float32)
+        dn.process_frame_(torch.from_numpy(h).to(dev), hx, out, seed=2024 + hop, stream_id0=0)
+    torch.cuda.synchronize()
+    assert np.array_equal(got, out.cpu().numpy())

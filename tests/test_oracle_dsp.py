@@ -73,3 +73,22 @@ def test_golden_dsp_fixture_is_reproduced():
     mi, peak = pipeline_ref.analysis(torch.from_numpy(g["frames"]), p, torch.from_numpy(g["fb"]))
     assert np.abs(mi.numpy() - g["model_input"]).max() <= 1e-4
     assert peak[4] == 1.0 and peak[5] == 1.0
+
+
+@pytest.mark.parametrize("p", [pipeline_ref.PARAMS_S, pipeline_ref.PARAMS_R1], ids=["S", "R1"])
+def test_third_opinion_scipy_signal(p):
+    """A third, unrelated implementation: scipy.signal.stft / istft (even-extension boundary == reflect padding, periodic
+    Hann, 50 % overlap) agrees with the restatement of torch.stft / torch.istft once its 1/sum(window) scaling is undone."""
+    import scipy.signal as ss
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, p.n_fft, generator=g)
+    win = ss.get_window("hann", p.n_fft, fftbins=True)
+    assert np.abs(win - dsp_np64.hann(p.n_fft)).max() <= 1e-12
+    _, _, Z = ss.stft(x.numpy().astype(np.float64), nperseg=p.n_fft, noverlap=p.n_fft - p.hop, window=win, boundary="even",
+                      padded=False, return_onesided=True)
+    Z = Z * win.sum()
+    s = dsp_ref.spectrogram(x, p.n_fft, p.hop).numpy()
+    assert Z.shape == s.shape and np.abs(Z - s).max() <= 2e-4 * np.abs(Z).max()
+    _, y = ss.istft(Z / win.sum(), nperseg=p.n_fft, noverlap=p.n_fft - p.hop, window=win, boundary=True, input_onesided=True)
+    y_ref = dsp_ref.inverse_spectrogram(torch.from_numpy(s), p.n_fft, p.hop).numpy()
+    assert np.abs(y[:, :p.n_fft] - y_ref).max() <= 1e-4
