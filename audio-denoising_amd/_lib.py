@@ -16,20 +16,22 @@ import threading
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdn_denoise.so")
+# DN_LIB_PATH binds another build of the same sources (the stamped diagnostic build of tools/gl_probe.py); unset = the product
+LIB_PATH = os.environ.get("DN_LIB_PATH") or os.path.join(_HERE, "lib", "libdn_denoise.so")
 
 # every symbol include/dn_denoise.h declares
 SYMBOLS = (
     "dn_model_create", "dn_model_destroy", "dn_cell_forward", "dn_cell_forward_ex", "dn_cell_forward_bf16", "dn_stft_general", "dn_server_rows", "dn_istft_general", "dn_dsp_create", "dn_dsp_destroy",
     "dn_dsp_get_tables", "dn_stft", "dn_stft_mel_log1p", "dn_mel_scale", "dn_invmel", "dn_residual_invmel",
     "dn_griffinlim", "dn_synthesis", "dn_istft", "dn_workspace_bytes", "dn_process_frame", "dn_stream_step",
-    "dn_pipe_create", "dn_pipe_destroy", "dn_pipe_submit", "dn_pipe_flush", "dn_pipe_stream_create", "dn_pipe_stream_push",
+    "dn_pipe_create", "dn_pipe_destroy", "dn_pipe_set_model", "dn_pipe_reserve_parity", "dn_pipe_get_counters", "dn_pipe_submit", "dn_pipe_flush", "dn_pipe_stream_create", "dn_pipe_stream_push",
     "dn_pipe_stream_flush", "dn_pipe_stream_get_state", "dn_pipe_stream_set_state", "dn_last_error", "dn_abi_version",
 )
 
 DN_PEAK_NORMALIZE = 1
 DN_PRE_WINDOW = 2
-ABI_VERSION = 1
+DN_CONV_BF16 = 1
+ABI_VERSION = 2
 
 
 class ModelCfg(C.Structure):
@@ -84,18 +86,21 @@ class DnLib:
         L.dn_istft.argtypes = [vp, p, p, i32, vp]
         L.dn_workspace_bytes.argtypes = [vp, i32]
         L.dn_workspace_bytes.restype = C.c_size_t
-        L.dn_process_frame.argtypes = [vp, vp, p, p, p, p, p, u64, u64, i32, f32, vp, i32, vp]
-        L.dn_stream_step.argtypes = [vp, vp, p, p, p, p, p, p, u64, u64, i32, f32, vp, i32, vp]
-        L.dn_pipe_create.argtypes = [vp, vp, i32, C.POINTER(vp)]
+        L.dn_process_frame.argtypes = [vp, vp, p, p, p, p, p, u64, u64, i32, f32, vp, i32, u32, vp]
+        L.dn_stream_step.argtypes = [vp, vp, p, p, p, p, p, p, u64, u64, i32, f32, vp, i32, u32, vp]
+        L.dn_pipe_create.argtypes = [vp, vp, i32, u32, C.POINTER(vp)]
         L.dn_pipe_destroy.argtypes = [vp]
         L.dn_pipe_destroy.restype = None
+        L.dn_pipe_set_model.argtypes = [vp, vp]
+        L.dn_pipe_reserve_parity.argtypes = [vp]
+        L.dn_pipe_get_counters.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(i32), vp]
         L.dn_pipe_submit.argtypes = [vp, p, p, p, p, u64, u64, i32, f32, vp]
-        L.dn_pipe_flush.argtypes = [vp, vp]
-        L.dn_pipe_stream_create.argtypes = [vp, vp, i32, C.POINTER(vp)]
+        L.dn_pipe_flush.argtypes = [vp, i32, f32, vp]
+        L.dn_pipe_stream_create.argtypes = [vp, vp, i32, u32, C.POINTER(vp)]
         L.dn_pipe_stream_push.argtypes = [vp, p, i32, p, i32, p, u64, u64, i32, f32, vp]
-        L.dn_pipe_stream_flush.argtypes = [vp, p, i32, vp]
+        L.dn_pipe_stream_flush.argtypes = [vp, p, i32, i32, f32, vp]
         L.dn_pipe_stream_get_state.argtypes = [vp, p, p, p, vp]
-        L.dn_pipe_stream_set_state.argtypes = [vp, p, p, p, vp]
+        L.dn_pipe_stream_set_state.argtypes = [vp, p, p, p, u64, vp]
         if L.dn_abi_version() != ABI_VERSION:
             raise ImportError(f"{path}: ABI version {L.dn_abi_version()} != {ABI_VERSION}; rebuild the extension")
 

@@ -3,6 +3,7 @@
 #include <math.h>
 #include <string.h>
 
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <string>
@@ -109,6 +110,7 @@ struct BiasSet {
 }  // namespace
 
 struct dn_model {
+    std::atomic<int> refs{1};  // the creator's reference + one per dn_pipe bound to it (dn_model_destroy only drops the creator's)
     dn_model_cfg cfg;
     std::vector<float> w;      // the caller's flat state_dict
     DevArena packed;           // MFMA weight fragments (fp32 and bf16), recurrent and last-level weights
@@ -119,6 +121,7 @@ struct dn_model {
 };
 
 struct dn_dsp {
+    std::atomic<int> refs{1};
     dn_dsp_cfg cfg;
     DevArena arena;
     dn::DspDev view;
@@ -126,19 +129,19 @@ struct dn_dsp {
 };
 
 struct dn_pipe {
-    const dn_model* m = nullptr;
-    const dn_dsp* d = nullptr;
+    dn_model* m = nullptr;
+    dn_dsp* d = nullptr;
     int B = 0, C = 0;
-    float* scratch[2] = {nullptr, nullptr};   // per slot: mel [B][3][M], residual [B][3][M], peak [B], lin [B][3][K]
-    uint64_t seq = 0;
+    bool bf16 = false;                        // DN_CONV_BF16: bf16 MFMA conv tiles in the front half
+    dn::PipeCtl* ctl = nullptr;               // device-resident hop counter / pending flag (what makes a captured launch replayable)
+    float* scratch[2] = {nullptr, nullptr};   // per slot: mel [B][3][M], residual [B][3][M], peak [B], meta [B][8], lin [B][3][K]
+    float2* scratch_init[2] = {nullptr, nullptr};   // per slot: the frame's initial phases (allocated on first parity-mode use)
     BiasSet* bs = nullptr;
-    bool pending = false;                     // a hop whose Griffin-Lim has not been launched yet
-    dn::HopArgs last{};                       // its back-half arguments
+    float* last_out = nullptr;                // frame mode: where the pending hop's frames go
     // streaming mode: per-stream state owned by the pipe
     float* ring = nullptr;                    // [B][n_fft] last n_fft input samples
     float* ola = nullptr;                     // [B][n_fft] output overlap-add line
     float* hx = nullptr;                      // [B][17][C]
-    uint64_t pushes = 0;
 };
 
 namespace {
@@ -357,12 +360,15 @@ int dn_model_create(const float* weights, size_t n_floats, const dn_model_cfg* c
     return DN_OK;
 }
 
-void dn_model_destroy(dn_model* m) {
-    if (!m) return;
+static void model_release(dn_model* m) {
+    if (!m || m->refs.fetch_sub(1) != 1) return;
     for (auto& kv : m->bias) { kv.second->arena.release(); delete kv.second; }
     m->packed.release();
     delete m;
 }
+
+// Drops the creator's reference; the device arenas are freed once no dn_pipe is bound to the model any more.
+void dn_model_destroy(dn_model* m) { model_release(m); }
 
 int dn_cell_forward(const dn_model* m, const float* x, const float* hx_in, float* out, float* hx_out, int32_t B,
                     int32_t T, int32_t F, int32_t C, void* stream) {
@@ -512,11 +518,13 @@ int dn_dsp_create(const dn_dsp_cfg* cfg, const float* fb_in, const float* pinv_i
     return DN_OK;
 }
 
-void dn_dsp_destroy(dn_dsp* d) {
-    if (!d) return;
+static void dsp_release(dn_dsp* d) {
+    if (!d || d->refs.fetch_sub(1) != 1) return;
     d->arena.release();
     delete d;
 }
+
+void dn_dsp_destroy(dn_dsp* d) { dsp_release(d); }
 
 int dn_dsp_get_tables(const dn_dsp* d, float* fb, float* pinv, float* window) {
     if (!d) return fail(DN_ERR_INVALID, "dn_dsp_get_tables: null plan");
@@ -643,87 +651,119 @@ size_t dn_workspace_bytes(const dn_dsp* d, int32_t B) {
     return frame_scratch_bytes(d, B) + (((size_t)B * d->cfg.n_fft * sizeof(float) + 255) & ~size_t(255));
 }
 
+static int check_hop_args(const char* who, const dn_model* m, const dn_dsp* d, int32_t B, int32_t n_iter, float momentum, uint32_t flags) {
+    if (!m || !d) return fail(DN_ERR_INVALID, std::string(who) + ": null handle");
+    if (d->cfg.n_mels <= 0 || d->cfg.n_mels % 16) return fail(DN_ERR_INVALID, "n_mels must be a positive multiple of 16");
+    if (B < 0 || n_iter < 0) return fail(DN_ERR_INVALID, std::string(who) + ": negative size");
+    if (!(momentum >= 0.0f && momentum < 1.0f)) return fail(DN_ERR_INVALID, "momentum must be in [0, 1)");
+    if (d->cfg.n_mels / 16 > dn::kMaxC) return fail(DN_ERR_UNSUPPORTED, "n_mels/16 exceeds the cell kernel's limit");
+    if (flags & ~(uint32_t)DN_CONV_BF16) return fail(DN_ERR_INVALID, std::string(who) + ": unknown flag bits");
+    return DN_OK;
+}
+
 int dn_process_frame(const dn_model* m, const dn_dsp* d, const float* frames, float* hx, float* out, float* mel_residual_out,
                      const float* init_angles, uint64_t seed, uint64_t stream_id0, int32_t n_iter, float momentum,
-                     void* workspace, int32_t B, void* stream) {
+                     void* workspace, int32_t B, uint32_t flags, void* stream) {
     if (B == 0) return DN_OK;      // empty batch: nothing to do (pointers of empty tensors are null)
-    if (!m || !d || !frames || !hx || !out || !workspace) return fail(DN_ERR_INVALID, "dn_process_frame: null argument");
-    if (d->cfg.n_mels <= 0 || d->cfg.n_mels % 16) return fail(DN_ERR_INVALID, "n_mels must be a positive multiple of 16");
-    if (B < 0 || n_iter < 0) return fail(DN_ERR_INVALID, "dn_process_frame: negative size");
-    if (!(momentum >= 0.0f && momentum < 1.0f)) return fail(DN_ERR_INVALID, "momentum must be in [0, 1)");
-    if (B == 0) return DN_OK;
-    const int M = d->cfg.n_mels, K = d->cfg.n_fft / 2 + 1, C = M / 16;
-    if (C > dn::kMaxC) return fail(DN_ERR_UNSUPPORTED, "n_mels/16 exceeds the cell kernel's limit");
-    float* ws = static_cast<float*>(workspace);
-    float* mel_in = ws;
-    float* diff = mel_residual_out ? mel_residual_out : mel_in + (size_t)B * 3 * M;
-    float* peak = mel_in + (size_t)B * 6 * M + (size_t)B * 3 * K;
-    BiasSet* bs = nullptr;
-    int rc = build_bias(const_cast<dn_model*>(m), C, &bs);
+    if (!frames || !hx || !out || !workspace) return fail(DN_ERR_INVALID, "dn_process_frame: null argument");
+    int rc = check_hop_args("dn_process_frame", m, d, B, n_iter, momentum, flags);
     if (rc != DN_OK) return rc;
-    hipStream_t st = as_stream(stream);
-    dn::launch_stft(d->view, frames, nullptr, mel_in, peak, B, DN_PEAK_NORMALIZE | DN_PRE_WINDOW, st);      // P1-P6
-    if ((rc = check_launch("stft_kernel")) != DN_OK) return rc;
-    dn::launch_cell(bs->view, mel_in, hx, diff, hx, B, 3, C, st);                                          // P7
-    if ((rc = check_launch("cell_kernel")) != DN_OK) return rc;
-    // P8-P12 in one launch: the inverse-mel contraction is the Griffin-Lim kernel's prologue (magnitudes stay in LDS)
-    dn::launch_synthesis(d->view, mel_in, diff, init_angles, seed, stream_id0, peak, out, B, n_iter, momentum, st);
-    return check_launch("griffinlim_kernel<from mel>");
+    const int M = d->cfg.n_mels, K = d->cfg.n_fft / 2 + 1, C = M / 16;
+    float* ws = static_cast<float*>(workspace);
+    BiasSet* bs = nullptr;
+    rc = build_bias(const_cast<dn_model*>(m), C, &bs);
+    if (rc != DN_OK) return rc;
+    dn::FrameArgs a{};
+    a.frames = frames; a.hx = hx; a.out = out;
+    a.mel = ws;
+    a.diff = mel_residual_out ? mel_residual_out : ws + (size_t)B * 3 * M;
+    a.peak = ws + (size_t)B * 6 * M + (size_t)B * 3 * K;
+    a.init = init_angles; a.seed = seed; a.sid0 = stream_id0;
+    a.n_iter = n_iter; a.mom = momentum / (1.0f + momentum); a.C = C;
+    dn::launch_frame(d->view, bs->view, a, B, (flags & DN_CONV_BF16) != 0, as_stream(stream));      // P1-P12, one launch
+    return check_launch("frame_kernel");
 }
 
 int dn_stream_step(const dn_model* m, const dn_dsp* d, const float* hop_in, float* ring, float* ola, float* hx, float* hop_out,
                    const float* init_angles, uint64_t seed, uint64_t stream_id0, int32_t n_iter, float momentum, void* workspace,
-                   int32_t B, void* stream) {
+                   int32_t B, uint32_t flags, void* stream) {
     if (B == 0) return DN_OK;      // empty batch: nothing to do (pointers of empty tensors are null)
-    if (!hop_in || !ring || !ola || !hop_out || !workspace) return fail(DN_ERR_INVALID, "dn_stream_step: null argument");
-    if (B < 0) return fail(DN_ERR_INVALID, "dn_stream_step: negative batch");
-    if (B == 0) return DN_OK;
-    hipStream_t st = as_stream(stream);
-    if (!d) return fail(DN_ERR_INVALID, "dn_stream_step: null plan");
-    dn::launch_stream_shift(d->cfg.n_fft, hop_in, ring, B, st);
-    int rc = check_launch("stream_shift_kernel");
+    // every argument is validated before the first (and only) launch, so a failed call leaves ring, ola and hx untouched
+    if (!hop_in || !ring || !ola || !hx || !hop_out || !workspace) return fail(DN_ERR_INVALID, "dn_stream_step: null argument");
+    int rc = check_hop_args("dn_stream_step", m, d, B, n_iter, momentum, flags);
     if (rc != DN_OK) return rc;
-    // the denoised frame lands at the head of the workspace tail (after the process_frame scratch)
-    if (!d) return fail(DN_ERR_INVALID, "dn_stream_step: null plan");
-    float* y = reinterpret_cast<float*>(static_cast<char*>(workspace) + frame_scratch_bytes(d, B));
-    rc = dn_process_frame(m, d, ring, hx, y, nullptr, init_angles, seed, stream_id0, n_iter, momentum, workspace, B, stream);
+    const int M = d->cfg.n_mels, K = d->cfg.n_fft / 2 + 1, C = M / 16;
+    float* ws = static_cast<float*>(workspace);
+    BiasSet* bs = nullptr;
+    rc = build_bias(const_cast<dn_model*>(m), C, &bs);
     if (rc != DN_OK) return rc;
-    dn::launch_stream_ola(d->cfg.n_fft, y, ola, hop_out, B, st);
-    return check_launch("stream_ola_kernel");
+    dn::FrameArgs a{};
+    a.hx = hx;
+    a.mel = ws; a.diff = ws + (size_t)B * 3 * M; a.peak = ws + (size_t)B * 6 * M + (size_t)B * 3 * K;
+    a.init = init_angles; a.seed = seed; a.sid0 = stream_id0;
+    a.n_iter = n_iter; a.mom = momentum / (1.0f + momentum); a.C = C;
+    a.hop_in = hop_in; a.ring = ring; a.ola = ola; a.hop_out = hop_out;
+    dn::launch_frame(d->view, bs->view, a, B, (flags & DN_CONV_BF16) != 0, as_stream(stream));
+    return check_launch("frame_kernel(stream)");
 }
 
-int dn_pipe_create(const dn_model* m, const dn_dsp* d, int32_t B, dn_pipe** out) {
-    if (!m || !d || !out) return fail(DN_ERR_INVALID, "dn_pipe_create: null argument");
+// ------------------------------------------------------------------ software-pipelined hops
+static size_t slot_floats(const dn_dsp* d, int32_t B) {
+    return (size_t)B * (6 * (size_t)d->cfg.n_mels + 1 + 8 + 3 * ((size_t)d->cfg.n_fft / 2 + 1));
+}
+
+int dn_pipe_create(const dn_model* m, const dn_dsp* d, int32_t B, uint32_t flags, dn_pipe** out) {
+    if (!out) return fail(DN_ERR_INVALID, "dn_pipe_create: null argument");
     if (B <= 0) return fail(DN_ERR_INVALID, "dn_pipe_create: batch must be positive");
-    if (d->cfg.n_mels <= 0 || d->cfg.n_mels % 16) return fail(DN_ERR_INVALID, "n_mels must be a positive multiple of 16");
-    const int C = d->cfg.n_mels / 16;
-    if (C > dn::kMaxC) return fail(DN_ERR_UNSUPPORTED, "n_mels/16 exceeds the cell kernel's limit");
+    int rc = check_hop_args("dn_pipe_create", m, d, B, 0, 0.0f, flags);
+    if (rc != DN_OK) return rc;
     dn_pipe* p = new dn_pipe();
-    p->m = m; p->d = d; p->B = B; p->C = C;
-    int rc = build_bias(const_cast<dn_model*>(m), C, &p->bs);
-    if (rc != DN_OK) { delete p; return rc; }
-    const size_t slot = ((size_t)B * (6 * d->cfg.n_mels + 1 + 3 * (d->cfg.n_fft / 2 + 1)) * sizeof(float) + 255) & ~size_t(255);
-    for (int i = 0; i < 2; ++i) {
-        hipError_t e = hipMalloc(reinterpret_cast<void**>(&p->scratch[i]), slot);
-        if (e != hipSuccess) { dn_pipe_destroy(p); return fail(DN_ERR_HIP, std::string("dn_pipe_create: ") + hipGetErrorString(e)); }
-    }
+    p->m = const_cast<dn_model*>(m); p->d = const_cast<dn_dsp*>(d); p->B = B; p->C = d->cfg.n_mels / 16;
+    p->bf16 = (flags & DN_CONV_BF16) != 0;
+    p->m->refs.fetch_add(1);       // the pipe keeps the packed weights and the plan alive (its launches read their device arenas)
+    p->d->refs.fetch_add(1);
+    rc = build_bias(p->m, p->C, &p->bs);
+    if (rc != DN_OK) { dn_pipe_destroy(p); return rc; }
+    const size_t slot = (slot_floats(d, B) * sizeof(float) + 255) & ~size_t(255);
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&p->ctl), 256);
+    if (e == hipSuccess) e = hipMemset(p->ctl, 0, 256);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipMalloc(reinterpret_cast<void**>(&p->scratch[i]), slot);
+    if (e != hipSuccess) { dn_pipe_destroy(p); return fail(DN_ERR_HIP, std::string("dn_pipe_create: ") + hipGetErrorString(e)); }
     *out = p;
     return DN_OK;
 }
 
 void dn_pipe_destroy(dn_pipe* p) {
     if (!p) return;
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
         if (p->scratch[i]) (void)hipFree(p->scratch[i]);
+        if (p->scratch_init[i]) (void)hipFree(p->scratch_init[i]);
+    }
+    if (p->ctl) (void)hipFree(p->ctl);
     if (p->ring) (void)hipFree(p->ring);
     if (p->ola) (void)hipFree(p->ola);
     if (p->hx) (void)hipFree(p->hx);
+    model_release(p->m);
+    dsp_release(p->d);
     delete p;
 }
 
-int dn_pipe_stream_create(const dn_model* m, const dn_dsp* d, int32_t B, dn_pipe** out) {
+int dn_pipe_set_model(dn_pipe* p, const dn_model* m) {
+    if (!p || !m) return fail(DN_ERR_INVALID, "dn_pipe_set_model: null argument");
+    if (m == p->m) return DN_OK;
+    BiasSet* bs = nullptr;
+    int rc = build_bias(const_cast<dn_model*>(m), p->C, &bs);
+    if (rc != DN_OK) return rc;
+    const_cast<dn_model*>(m)->refs.fetch_add(1);
+    model_release(p->m);           // launches already enqueued read the old arenas: the caller keeps the old model alive until they ran
+    p->m = const_cast<dn_model*>(m);
+    p->bs = bs;
+    return DN_OK;
+}
+
+int dn_pipe_stream_create(const dn_model* m, const dn_dsp* d, int32_t B, uint32_t flags, dn_pipe** out) {
     dn_pipe* p = nullptr;
-    int rc = dn_pipe_create(m, d, B, &p);
+    int rc = dn_pipe_create(m, d, B, flags, &p);
     if (rc != DN_OK) return rc;
     const size_t line = (size_t)B * d->cfg.n_fft * sizeof(float), hxb = (size_t)B * dn::kHidden * p->C * sizeof(float);
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&p->ring), line);
@@ -751,100 +791,103 @@ int dn_pipe_stream_get_state(dn_pipe* p, float* ring, float* ola, float* hx, voi
     return stream_state_copy(p, ring, ola, hx, false, stream);
 }
 
-int dn_pipe_stream_set_state(dn_pipe* p, const float* ring, const float* ola, const float* hx, void* stream) {
-    if (p && p->pending) return fail(DN_ERR_INVALID, "dn_pipe_stream_set_state: flush the pending hop first");
+int dn_pipe_stream_set_state(dn_pipe* p, const float* ring, const float* ola, const float* hx, uint64_t frames_done, void* stream) {
     int rc = stream_state_copy(p, const_cast<float*>(ring), const_cast<float*>(ola), const_cast<float*>(hx), true, stream);
-    if (rc == DN_OK && ring) p->pushes = (uint64_t)(p->d->cfg.n_fft / p->d->cfg.hop - 1);   // a restored ring is a primed ring
-    return rc;
+    if (rc != DN_OK) return rc;
+    // a restored ring is a primed ring; a hop that was pending is dropped (flush before taking a snapshot)
+    dn::launch_ctl_set(p->ctl, (unsigned long long)(p->d->cfg.n_fft / p->d->cfg.hop - 1), frames_done, 0, as_stream(stream));
+    return check_launch("ctl_set_kernel");
+}
+
+int dn_pipe_get_counters(dn_pipe* p, uint64_t* pushes, uint64_t* frames, int32_t* pending, void* stream) {
+    if (!p) return fail(DN_ERR_INVALID, "dn_pipe_get_counters: null pipe");
+    dn::PipeCtl h{};
+    DN_HIP(hipMemcpyAsync(&h, p->ctl, sizeof(h), hipMemcpyDeviceToHost, as_stream(stream)));
+    DN_HIP(hipStreamSynchronize(as_stream(stream)));
+    if (pushes) *pushes = h.pushes;
+    if (frames) *frames = h.frames;
+    if (pending) *pending = (int32_t)h.pending;
+    return DN_OK;
+}
+
+// parity mode: a frame's injected phases travel with its scratch slot (so the caller's buffer is free again after the push)
+int dn_pipe_reserve_parity(dn_pipe* p) {
+    if (!p) return fail(DN_ERR_INVALID, "dn_pipe_reserve_parity: null pipe");
+    const size_t bytes = (size_t)p->B * 3 * (p->d->cfg.n_fft / 2 + 1) * sizeof(float2);
+    for (int i = 0; i < 2; ++i)
+        if (!p->scratch_init[i]) DN_HIP(hipMalloc(reinterpret_cast<void**>(&p->scratch_init[i]), bytes));
+    return DN_OK;
+}
+
+// the parts of a launch that are the same for every kind of push/submit/flush
+static int fill_hop_args(dn_pipe* p, dn::HopArgs& a, const float* init_angles, uint64_t seed, uint64_t stream_id0, int32_t n_iter,
+                         float momentum) {
+    if (n_iter < 0) return fail(DN_ERR_INVALID, "negative n_iter");
+    if (!(momentum >= 0.0f && momentum < 1.0f)) return fail(DN_ERR_INVALID, "momentum must be in [0, 1)");
+    if (init_angles && !p->scratch_init[1]) {
+        int rc = dn_pipe_reserve_parity(p);
+        if (rc != DN_OK) return rc;
+    }
+    a.ctl = p->ctl;
+    for (int i = 0; i < 2; ++i) { a.slot[i] = p->scratch[i]; a.slot_init[i] = p->scratch_init[i]; }
+    a.init_in = init_angles; a.seed = seed; a.sid0 = stream_id0;
+    a.n_iter = n_iter; a.mom = momentum / (1.0f + momentum);
+    a.B = p->B; a.C = p->C; a.back_B = p->B;
+    a.prime = p->d->cfg.n_fft / p->d->cfg.hop - 1;
+    return DN_OK;
 }
 
 int dn_pipe_stream_push(dn_pipe* p, const void* hop_in, int32_t in_is_s16, void* hop_out, int32_t out_is_s16,
                         const float* init_angles, uint64_t seed, uint64_t stream_id0, int32_t n_iter, float momentum, void* stream) {
     if (!p || !p->ring) return fail(DN_ERR_INVALID, "dn_pipe_stream_push: not a streaming pipe");
     if (!hop_in || !hop_out) return fail(DN_ERR_INVALID, "dn_pipe_stream_push: null argument");
-    if (n_iter < 0) return fail(DN_ERR_INVALID, "dn_pipe_stream_push: negative n_iter");
-    if (!(momentum >= 0.0f && momentum < 1.0f)) return fail(DN_ERR_INVALID, "momentum must be in [0, 1)");
-    const int B = p->B, M = p->d->cfg.n_mels, hop = p->d->cfg.hop;
-    const uint64_t prime = (uint64_t)(p->d->cfg.n_fft / hop - 1);       // pushes that only fill the ring
-    const bool priming = p->pushes < prime;
-    dn::HopArgs a = p->last;                       // back half: the frame submitted by the previous push (if any)
-    a.back_B = p->pending ? B : 0;
-    a.ola = p->ola; a.hop_out = hop_out; a.out_s16 = out_is_s16;
-    if (!p->pending)                               // nothing is emitted yet: the reference's ola[:hop] is still zero
-        DN_HIP(hipMemsetAsync(hop_out, 0, (size_t)B * hop * (out_is_s16 ? 2 : 4), as_stream(stream)));
-    const int s = (int)(p->seq & 1);
-    a.frames = nullptr; a.hx = p->hx;
-    a.mel = p->scratch[s];
-    a.diff = a.mel + (size_t)B * 3 * M;
-    a.peak = a.diff + (size_t)B * 3 * M;
-    a.lin = a.peak + B;
-    a.front_B = B; a.C = p->C;
-    a.hop_in = hop_in; a.ring = p->ring; a.in_s16 = in_is_s16; a.prime_only = priming ? 1 : 0;
-    dn::launch_hop(p->d->view, p->bs->view, a, as_stream(stream));
-    int rc = check_launch("hop_kernel(stream)");
+    dn::HopArgs a{};
+    int rc = fill_hop_args(p, a, init_angles, seed, stream_id0, n_iter, momentum);
     if (rc != DN_OK) return rc;
-    p->pushes++;
-    if (priming) { p->pending = false; return DN_OK; }
-    p->last.gl_lin = a.lin; p->last.gl_peak = a.peak; p->last.gl_init = init_angles;
-    p->last.gl_seed = seed; p->last.gl_sid0 = stream_id0; p->last.gl_out = nullptr;
-    p->last.n_iter = n_iter; p->last.mom = momentum / (1.0f + momentum);
-    p->pending = true;
-    p->seq++;
-    return DN_OK;
+    a.front_B = p->B; a.hx = p->hx;
+    a.hop_in = hop_in; a.ring = p->ring; a.in_s16 = in_is_s16;
+    a.ola = p->ola; a.hop_out = hop_out; a.out_s16 = out_is_s16;
+    dn::launch_hop(p->d->view, p->bs->view, a, p->bf16, as_stream(stream));
+    return check_launch("hop_kernel(stream)");
 }
 
-int dn_pipe_stream_flush(dn_pipe* p, void* hop_out, int32_t out_is_s16, void* stream) {
+int dn_pipe_stream_flush(dn_pipe* p, void* hop_out, int32_t out_is_s16, int32_t n_iter, float momentum, void* stream) {
     if (!p || !p->ring) return fail(DN_ERR_INVALID, "dn_pipe_stream_flush: not a streaming pipe");
     if (!hop_out) return fail(DN_ERR_INVALID, "dn_pipe_stream_flush: null argument");
-    if (!p->pending) {
-        DN_HIP(hipMemsetAsync(hop_out, 0, (size_t)p->B * p->d->cfg.hop * (out_is_s16 ? 2 : 4), as_stream(stream)));
-        return DN_OK;
-    }
-    dn::HopArgs a = p->last;
-    a.back_B = p->B; a.front_B = 0; a.C = p->C;
+    dn::HopArgs a{};
+    int rc = fill_hop_args(p, a, nullptr, 0, 0, n_iter, momentum);
+    if (rc != DN_OK) return rc;
+    a.front_B = 0;
     a.ola = p->ola; a.hop_out = hop_out; a.out_s16 = out_is_s16;
-    a.ring = nullptr; a.hop_in = nullptr;
-    dn::launch_hop(p->d->view, p->bs->view, a, as_stream(stream));
-    p->pending = false;
+    dn::launch_hop(p->d->view, p->bs->view, a, p->bf16, as_stream(stream));
     return check_launch("hop_kernel(stream flush)");
 }
 
 int dn_pipe_submit(dn_pipe* p, const float* frames, float* hx, float* out, const float* init_angles, uint64_t seed,
                    uint64_t stream_id0, int32_t n_iter, float momentum, void* stream) {
     if (!p || !frames || !hx || !out) return fail(DN_ERR_INVALID, "dn_pipe_submit: null argument");
-    if (n_iter < 0) return fail(DN_ERR_INVALID, "dn_pipe_submit: negative n_iter");
-    if (!(momentum >= 0.0f && momentum < 1.0f)) return fail(DN_ERR_INVALID, "momentum must be in [0, 1)");
-    const int s = (int)(p->seq & 1), B = p->B, M = p->d->cfg.n_mels;
-    dn::HopArgs a = p->last;                       // back half: the hop submitted before this one (if any)
-    a.back_B = p->pending ? B : 0;
-    a.frames = frames; a.hx = hx;                  // front half: this hop, into scratch slot s
-    a.mel = p->scratch[s];
-    a.diff = a.mel + (size_t)B * 3 * M;
-    a.peak = a.diff + (size_t)B * 3 * M;
-    a.lin = a.peak + B;
-    a.front_B = B; a.C = p->C;
-    a.ring = nullptr; a.hop_in = nullptr; a.ola = nullptr; a.hop_out = nullptr; a.prime_only = 0;
-    dn::launch_hop(p->d->view, p->bs->view, a, as_stream(stream));
-    int rc = check_launch("hop_kernel");
+    if (p->ring) return fail(DN_ERR_INVALID, "dn_pipe_submit: this is a streaming pipe (use dn_pipe_stream_push)");
+    dn::HopArgs a{};
+    int rc = fill_hop_args(p, a, init_angles, seed, stream_id0, n_iter, momentum);
     if (rc != DN_OK) return rc;
-    // remember this hop's Griffin-Lim for the next launch
-    p->last.gl_lin = a.lin; p->last.gl_peak = a.peak; p->last.gl_init = init_angles;
-    p->last.gl_seed = seed; p->last.gl_sid0 = stream_id0; p->last.gl_out = out;
-    p->last.n_iter = n_iter; p->last.mom = momentum / (1.0f + momentum);
-    p->pending = true;
-    p->seq++;
+    a.front_B = p->B; a.frames = frames; a.hx = hx;
+    a.gl_out = p->last_out ? p->last_out : out;      // back half: the hop submitted before this one (none pending on the first launch)
+    dn::launch_hop(p->d->view, p->bs->view, a, p->bf16, as_stream(stream));
+    rc = check_launch("hop_kernel");
+    if (rc != DN_OK) return rc;
+    p->last_out = out;               // this hop's Griffin-Lim runs in the next launch
     return DN_OK;
 }
 
-int dn_pipe_flush(dn_pipe* p, void* stream) {
+int dn_pipe_flush(dn_pipe* p, int32_t n_iter, float momentum, void* stream) {
     if (!p) return fail(DN_ERR_INVALID, "dn_pipe_flush: null pipe");
-    if (!p->pending) return DN_OK;
-    dn::HopArgs a = p->last;
-    a.back_B = p->B; a.front_B = 0; a.C = p->C;
-    a.frames = nullptr; a.hx = nullptr; a.mel = nullptr; a.diff = nullptr; a.peak = nullptr; a.lin = nullptr;
-    a.ring = nullptr; a.hop_in = nullptr; a.ola = nullptr; a.hop_out = nullptr; a.prime_only = 0;
-    dn::launch_hop(p->d->view, p->bs->view, a, as_stream(stream));
-    p->pending = false;
+    if (p->ring) return fail(DN_ERR_INVALID, "dn_pipe_flush: this is a streaming pipe (use dn_pipe_stream_flush)");
+    if (!p->last_out) return DN_OK;  // nothing was ever submitted
+    dn::HopArgs a{};
+    int rc = fill_hop_args(p, a, nullptr, 0, 0, n_iter, momentum);
+    if (rc != DN_OK) return rc;
+    a.front_B = 0; a.gl_out = p->last_out;
+    dn::launch_hop(p->d->view, p->bs->view, a, p->bf16, as_stream(stream));
     return check_launch("hop_kernel(flush)");
 }
 

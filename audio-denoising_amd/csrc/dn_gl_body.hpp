@@ -9,6 +9,22 @@ namespace dn {
 
 constexpr int kGlThreads = 192;
 
+// Diagnostic build only (make probe: -DDN_PROBE): s_memtime stamps of one Griffin-Lim iteration of workgroup 0, stored to a
+// buffer of their own that nothing else reads (profiles/ holds the shares they gave; the product build has no stamp).
+#ifdef DN_PROBE
+static __device__ unsigned long long g_gl_probe[3][16];   // one copy per translation unit
+#define DN_STAMP(id)                                                                              \
+    do {                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        unsigned long long t_;                                                                    \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
+        if (b == 0 && it == 10 && lane == 0) g_gl_probe[W][id] = t_;                              \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+    } while (0)
+#else
+#define DN_STAMP(id) do { } while (0)
+#endif
+
 // Philox4x32-10 counter-based generator (Salmon et al. 2011).
 __device__ __forceinline__ void philox4x32(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
 #pragma unroll
@@ -166,8 +182,11 @@ __device__ __forceinline__ void gl_body(char* smem, const DspDev& d, const float
     xmid = amid * mmid;
     for (int it = 0;; ++it) {
         // ---- istft of X = angles * magnitude: Hermitian merge, inverse FFT, synthesis window, overlap-add lines
+        DN_STAMP(0);
         irfft_merge_pairs<kNV>(xlo, xhi, xmid, wkh, lane, v);
+        DN_STAMP(1);
         G::Fft::template run<true>(v, tw, mytile, lane);
+        DN_STAMP(2);
         float* y1 = ybuf[it & 1][0];
         float* yo = ybuf[it & 1][1];
         {
@@ -178,7 +197,9 @@ __device__ __forceinline__ void gl_body(char* smem, const DspDev& d, const float
 #pragma unroll
             for (int t = t_lo; t < t_hi; ++t) *reinterpret_cast<v2f*>(ydst + 2 * (lane + 64 * t)) = v[t] * wsyn[t];
         }
+        DN_STAMP(3);
         __syncthreads();
+        DN_STAMP(4);
         if (it == n_iter) {
             // final istft: divide by the window envelope, trim, scale (app3.py:217 `* peak`)
             const float sc = scale != nullptr ? scale[b] : 1.0f;
@@ -226,8 +247,11 @@ __device__ __forceinline__ void gl_body(char* smem, const DspDev& d, const float
             else { if (t < kNP) { i0 = n0 + kHop; i1 = i0 + 1; } else { i0 = 3 * kHop - 2 - n0; i1 = i0 - 1; } }
             v[t] = mk2(y1[i0] + yo[i0], y1[i1] + yo[i1]) * cw[t];
         }
+        DN_STAMP(5);
         G::Fft::template run<false>(v, tw, mytile, lane);
+        DN_STAMP(6);
         rfft_split_pairs<kNV>(v, wkh, lane, rlo, rhi, rmid);
+        DN_STAMP(7);
         // ---- phase update with momentum
 #pragma unroll
         for (int t = 0; t < kNP; ++t) {
@@ -235,6 +259,7 @@ __device__ __forceinline__ void gl_body(char* smem, const DspDev& d, const float
             update(rhi[t], phi[t], xhi[t], mhi[t]);
         }
         update(rmid, pmid, xmid, mmid);
+        DN_STAMP(8);
     }
     };
     if (w == 0) iterate(std::integral_constant<int, 0>{});

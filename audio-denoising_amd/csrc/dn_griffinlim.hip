@@ -50,3 +50,10 @@ void launch_synthesis(const DspDev& d, const float* x, const float* diff, const 
 }
 
 }  // namespace dn
+
+#ifdef DN_PROBE
+// diagnostic build only: the stamps of the stand-alone Griffin-Lim kernels of this translation unit
+extern "C" int dn_probe_read_gl(unsigned long long* host48) {
+    return (int)hipMemcpyFromSymbol(host48, HIP_SYMBOL(dn::g_gl_probe), sizeof(dn::g_gl_probe));
+}
+#endif

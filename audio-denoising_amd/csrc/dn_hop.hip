@@ -1,17 +1,22 @@
-// dn_hop.hip -- software-pipelined hop: ONE launch per hop that overlaps hop n's Griffin-Lim with hop n+1's
-// analysis + model + inverse mel (app3.py:178-217 for B streams, consecutive loop iterations overlapped).
+// dn_hop.hip -- the whole hop as ONE launch (app3.py:178-226 for B streams), in two schedules:
 //
-// Consecutive hops depend on each other only through hx (the model); hop n's Griffin-Lim (~3/4 of a hop, a
-// strictly serial chain per stream that occupies three wavefronts of a CU) does not depend on hop n+1's
-// front half.  A launch therefore carries two kinds of workgroups:
-//   blocks [0, back_B)           Griffin-Lim of the PREVIOUS hop, reading scratch slot s^1
-//   blocks [back_B, back_B + B)  P1-P10 of THIS hop (stft -> GRUUNet2 -> inverse mel, one stream per workgroup,
-//                                stages separated by workgroup barriers), writing scratch slot s
-// Both kinds are resident together (192 threads, <= 35 KB LDS, 204 VGPRs: a Griffin-Lim and a front workgroup
-// share a CU), so the front half fills issue slots and the fourth SIMD the latency-bound Griffin-Lim leaves
-// idle.  Everything is on the caller's stream: launch k+1 is ordered behind launch k, which is all the
-// synchronisation the slot hand-over needs -- no events, no second stream, no cross-queue latency
-// (a two-stream/event version of this overlap lost ~13 us per hop to cross-queue signalling).
+// frame_kernel   nothing overlapped: one workgroup per stream runs P1-P12 back to back (dn_process_frame, dn_stream_step).
+//
+// hop_kernel     software-pipelined: ONE launch per hop that overlaps hop n's Griffin-Lim with hop n+1's analysis + model +
+//                inverse mel (consecutive loop iterations of app3.py:178 overlapped; dn_pipe_*).
+//   Consecutive hops depend on each other only through hx (the model); hop n's Griffin-Lim (~3/4 of a hop, a
+//   strictly serial chain per stream that occupies three wavefronts of a CU) does not depend on hop n+1's
+//   front half.  A launch therefore carries two kinds of workgroups:
+//     blocks [0, back_B)           Griffin-Lim of the PENDING hop, reading scratch slot (frames-1) & 1
+//     blocks [back_B, back_B + B)  P1-P10 of THIS hop (stft -> GRUUNet2 -> inverse mel, one stream per workgroup,
+//                                  stages separated by workgroup barriers), writing scratch slot frames & 1
+//   Both kinds are resident together (192 threads, <= 35 KB LDS: a Griffin-Lim and a front workgroup share a CU),
+//   so the front half fills issue slots and the fourth SIMD the latency-bound Griffin-Lim leaves idle.  Everything is on
+//   the caller's stream: launch k+1 is ordered behind launch k, which is all the synchronisation the slot hand-over
+//   needs -- no events, no second stream (a two-stream/event version lost ~13 us per hop to cross-queue signalling).
+//   What changes from hop to hop -- the slot parity, the Griffin-Lim seed, whether a hop is pending, the ring priming
+//   of a new stream -- lives in a device-resident control block (PipeCtl) that the last workgroup of every launch
+//   advances, so one captured launch replays indefinitely under hipGraph (BASELINE config 5).
 #include "dn_cell_body.hpp"
 #include "dn_gl_body.hpp"
 #include "dn_invmel_body.hpp"
@@ -24,69 +29,206 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 template <int NFFT> constexpr int hop_smem() { return cmax(cmax(kCellSmem, gl_smem<NFFT>()), cmax(stft_smem<NFFT>(), kInvSmem)); }
 static_assert(kHopThreads == kGlThreads && kHopThreads == kStftThreads && kHopThreads == kInvThreads, "one block size for all bodies");
 
+// ring <- concat(ring[hop:], hop_in): every thread holds its float4s before anything is overwritten   (app3.py:174,226)
+template <int NFFT>
+__device__ __forceinline__ void ring_shift(float* ring, const void* hop_in, int in_s16, size_t b, int tid) {
+    constexpr int kNR = NFFT, kLine4 = kNR / 4, kHop4 = kNR / 8;
+    static_assert(kLine4 <= 2 * kHopThreads, "two float4 per thread cover the line");
+    float4* r4 = reinterpret_cast<float4*>(ring + b * kNR);
+    float4 v[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int i4 = tid + kHopThreads * r;
+        v[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i4 < kLine4 - kHop4) v[r] = r4[i4 + kHop4];
+        else if (i4 < kLine4) {
+            const int j4 = i4 - (kLine4 - kHop4);
+            if (in_s16) {      // int16 -> float32 / iinfo(int16).max   (app3.py:172)
+                const short4 q = reinterpret_cast<const short4*>(static_cast<const short*>(hop_in) + b * (kNR / 2))[j4];
+                v[r] = make_float4((float)q.x / 32767.0f, (float)q.y / 32767.0f, (float)q.z / 32767.0f, (float)q.w / 32767.0f);
+            } else {
+                v[r] = reinterpret_cast<const float4*>(static_cast<const float*>(hop_in) + b * (kNR / 2))[j4];
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int i4 = tid + kHopThreads * r;
+        if (i4 < kLine4) r4[i4] = v[r];
+    }
+    __syncthreads();
+}
+
+// offsets (in floats) of the parts of a scratch slot
+struct SlotLayout {
+    size_t diff, peak, meta, lin;
+    __host__ __device__ SlotLayout(int B, int M, int K) {
+        diff = (size_t)B * 3 * M; peak = 2 * diff; meta = peak + B; lin = meta + 8 * (size_t)B; (void)K;
+    }
+};
+
 // n_fft 1536: the Griffin-Lim body would take 330 registers and shut the front workgroup out of the CU; capping the
 // kernel at two waves per SIMD (256 registers, ~80 values spilled to scratch) keeps both halves resident (+30 % at 1024
 // streams).  n_fft 1024 fits in 229 registers without a cap (capping it costs 8 %).
-template <int NFFT>
+template <int NFFT, bool STREAM, bool BF16>
 __global__ __launch_bounds__(kHopThreads, NFFT == 1536 ? 2 : 1) void hop_kernel(DspDev d, CellDev cd, HopArgs a) {
-    constexpr int kNR = NFFT;
+    constexpr int kNR = NFFT, kBins = Geo<NFFT>::kBins;
     __shared__ __attribute__((aligned(16))) char smem[hop_smem<NFFT>()];
     const int tid = threadIdx.x;
+    // control block as the previous launch left it (uniform: scalar loads)
+    const unsigned long long pushes = a.ctl->pushes, frames = a.ctl->frames;
+    const unsigned int pending = a.ctl->pending;
+    const SlotLayout sl(a.B, d.n_mels, kBins);
+    const bool priming = STREAM && pushes < (unsigned long long)a.prime;
     if ((int)blockIdx.x < a.back_B) {
-        // the Griffin-Lim chain is the critical path of the launch: let its waves win issue arbitration against the
-        // front-half waves they share SIMDs with
-        __builtin_amdgcn_s_setprio(3);
-        if (a.ola == nullptr)
-            gl_body<NFFT, false, false>(smem, d, a.gl_lin, nullptr, reinterpret_cast<const v2f*>(a.gl_init), a.gl_seed, a.gl_sid0,
-                                        a.gl_peak, a.gl_out, a.n_iter, a.mom, blockIdx.x, tid);
-        else
-            gl_body<NFFT, false, true>(smem, d, a.gl_lin, nullptr, reinterpret_cast<const v2f*>(a.gl_init), a.gl_seed, a.gl_sid0,
-                                       a.gl_peak, nullptr, a.n_iter, a.mom, blockIdx.x, tid, a.ola, a.hop_out, a.out_s16);
+        const size_t b = blockIdx.x;
+        if (pending) {
+            // the Griffin-Lim chain is the critical path of the launch: let its waves win issue arbitration against the
+            // front-half waves they share SIMDs with
+            __builtin_amdgcn_s_setprio(3);
+            const int s = (int)((frames - 1) & 1);
+            const float* slot = a.slot[s];
+            const uint32_t* meta = reinterpret_cast<const uint32_t*>(slot + sl.meta) + 8 * b;
+            const v2f* init = meta[0] ? reinterpret_cast<const v2f*>(a.slot_init[s]) : nullptr;
+            const uint64_t seed = (uint64_t)meta[1] | ((uint64_t)meta[2] << 32);
+            const uint64_t sid0 = (uint64_t)meta[3] | ((uint64_t)meta[4] << 32);
+            if (!STREAM)
+                gl_body<NFFT, false, false>(smem, d, slot + sl.lin, nullptr, init, seed, sid0, slot + sl.peak, a.gl_out, a.n_iter, a.mom, b, tid);
+            else
+                gl_body<NFFT, false, true>(smem, d, slot + sl.lin, nullptr, init, seed, sid0, slot + sl.peak, nullptr, a.n_iter, a.mom, b, tid,
+                                           a.ola, a.hop_out, a.out_s16);
+            __builtin_amdgcn_s_setprio(0);
+        } else if (STREAM) {
+            // nothing to emit yet: the reference's ola[:hop] is still zero (app3.py:133,219)
+            for (int n = tid; n < kNR / 2; n += kHopThreads) {
+                if (a.out_s16) static_cast<short*>(a.hop_out)[b * (kNR / 2) + n] = 0;
+                else static_cast<float*>(a.hop_out)[b * (kNR / 2) + n] = 0.0f;
+            }
+        }
     } else {
         const size_t b = blockIdx.x - a.back_B;
-        const float* frames = a.frames;
-        if (a.ring != nullptr) {
-            // ring <- concat(ring[hop:], hop_in): every thread holds its float4s before anything is overwritten
-            constexpr int kLine4 = kNR / 4, kHop4 = kNR / 8;
-            static_assert(kLine4 <= 2 * kHopThreads, "two float4 per thread cover the line");
-            float4* r4 = reinterpret_cast<float4*>(a.ring + b * kNR);
-            float4 v[2];
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const int i4 = tid + kHopThreads * r;
-                v[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (i4 < kLine4 - kHop4) v[r] = r4[i4 + kHop4];
-                else if (i4 < kLine4) {
-                    const int j4 = i4 - (kLine4 - kHop4);
-                    if (a.in_s16) {      // int16 -> float32 / iinfo(int16).max   (app3.py:172)
-                        const short4 q = reinterpret_cast<const short4*>(static_cast<const short*>(a.hop_in) + b * (kNR / 2))[j4];
-                        v[r] = make_float4((float)q.x / 32767.0f, (float)q.y / 32767.0f, (float)q.z / 32767.0f, (float)q.w / 32767.0f);
-                    } else {
-                        v[r] = reinterpret_cast<const float4*>(static_cast<const float*>(a.hop_in) + b * (kNR / 2))[j4];
-                    }
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                const int i4 = tid + kHopThreads * r;
-                if (i4 < kLine4) r4[i4] = v[r];
-            }
-            __syncthreads();
-            if (a.prime_only) return;
-            frames = a.ring;
+        const float* frames_in = a.frames;
+        if (STREAM) {
+            ring_shift<NFFT>(a.ring, a.hop_in, a.in_s16, b, tid);
+            frames_in = a.ring;
         }
-        stft_body<NFFT, false, true>(smem, d, frames, nullptr, a.mel, a.peak, DN_PEAK_NORMALIZE | DN_PRE_WINDOW, b, tid);   // P1-P6
-        __syncthreads();
-        cell_body<kHopThreads / 64>(smem, cd, a.mel, a.hx, a.diff, a.hx, 3, a.C, b, tid);                                   // P7
-        __syncthreads();
-        invmel_body<NFFT, true>(smem, d, a.mel, a.diff, a.lin, 3 * a.front_B, b * 3, tid);                                  // P8-P10
+        if (!priming) {
+            const int s = (int)(frames & 1);
+            float* slot = a.slot[s];
+            stft_body<NFFT, false, true>(smem, d, frames_in, nullptr, slot, slot + sl.peak, DN_PEAK_NORMALIZE | DN_PRE_WINDOW, b, tid);   // P1-P6
+            __syncthreads();
+            cell_body<kHopThreads / 64, BF16>(smem, cd, slot, a.hx, slot + sl.diff, a.hx, 3, a.C, b, tid);                                // P7
+            __syncthreads();
+            invmel_body<NFFT, true>(smem, d, slot, slot + sl.diff, slot + sl.lin, 3 * a.B, b * 3, tid);                                   // P8-P10
+            // what this frame's Griffin-Lim (next launch) needs besides the magnitudes: its seed, its stream ids and, in parity mode, its phases
+            if (tid == 0) {
+                uint32_t* meta = reinterpret_cast<uint32_t*>(slot + sl.meta) + 8 * b;
+                const uint64_t seed = a.seed + frames;
+                meta[0] = a.init_in != nullptr ? 1u : 0u;
+                meta[1] = (uint32_t)seed;
+                meta[2] = (uint32_t)(seed >> 32);
+                meta[3] = (uint32_t)a.sid0;
+                meta[4] = (uint32_t)(a.sid0 >> 32);
+            }
+            if (a.init_in != nullptr) {
+                const float2* src = reinterpret_cast<const float2*>(a.init_in) + b * 3 * kBins;
+                float2* dst = a.slot_init[s] + b * 3 * kBins;
+                for (int i = tid; i < 3 * kBins; i += kHopThreads) dst[i] = src[i];
+            }
+        }
+    }
+    // ---- ticket: the last workgroup of the launch advances the control block (every workgroup has read it by then)
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned int t = atomicAdd(&a.ctl->done, 1u);
+        if (t == gridDim.x - 1) {
+            a.ctl->done = 0;
+            if (a.front_B > 0) {
+                a.ctl->pushes = pushes + 1;
+                if (!priming) {
+                    a.ctl->frames = frames + 1;
+                    a.ctl->pending = 1;
+                } else {
+                    a.ctl->pending = 0;
+                }
+            } else {
+                a.ctl->pending = 0;      // flush
+            }
+        }
     }
 }
 
-void launch_hop(const DspDev& d, const CellDev& c, const HopArgs& a, hipStream_t st) {
-    if (d.n_fft == 1536) hipLaunchKernelGGL(hop_kernel<1536>, dim3(a.back_B + a.front_B), dim3(kHopThreads), 0, st, d, c, a);
-    else hipLaunchKernelGGL(hop_kernel<1024>, dim3(a.back_B + a.front_B), dim3(kHopThreads), 0, st, d, c, a);
+template <int NFFT, bool STREAM>
+static void launch_hop_n(const DspDev& d, const CellDev& c, const HopArgs& a, bool bf16, hipStream_t st) {
+    const dim3 grid(a.back_B + a.front_B), block(kHopThreads);
+    if (bf16) hipLaunchKernelGGL((hop_kernel<NFFT, STREAM, true>), grid, block, 0, st, d, c, a);
+    else hipLaunchKernelGGL((hop_kernel<NFFT, STREAM, false>), grid, block, 0, st, d, c, a);
+}
+
+void launch_hop(const DspDev& d, const CellDev& c, const HopArgs& a, bool bf16, hipStream_t st) {
+    const bool stream = a.ola != nullptr;
+    if (d.n_fft == 1536) {
+        if (stream) launch_hop_n<1536, true>(d, c, a, bf16, st);
+        else launch_hop_n<1536, false>(d, c, a, bf16, st);
+    } else {
+        if (stream) launch_hop_n<1024, true>(d, c, a, bf16, st);
+        else launch_hop_n<1024, false>(d, c, a, bf16, st);
+    }
+}
+
+__global__ void ctl_set_kernel(PipeCtl* ctl, unsigned long long pushes, unsigned long long frames, unsigned int pending) {
+    ctl->pushes = pushes; ctl->frames = frames; ctl->pending = pending; ctl->done = 0;
+}
+void launch_ctl_set(PipeCtl* ctl, unsigned long long pushes, unsigned long long frames, unsigned int pending, hipStream_t st) {
+    hipLaunchKernelGGL(ctl_set_kernel, dim3(1), dim3(1), 0, st, ctl, pushes, frames, pending);
+}
+
+// ---- the unpipelined hop: P1-P12 of one stream in one workgroup, one launch per hop (zero added latency)
+template <int NFFT, bool STREAM, bool BF16>
+__global__ __launch_bounds__(kHopThreads, NFFT == 1536 ? 2 : 1) void frame_kernel(DspDev d, CellDev cd, FrameArgs a) {
+    __shared__ __attribute__((aligned(16))) char smem[hop_smem<NFFT>()];
+    const int tid = threadIdx.x;
+    const size_t b = blockIdx.x;
+    const float* frames_in = a.frames;
+    if (STREAM) {
+        ring_shift<NFFT>(a.ring, a.hop_in, 0, b, tid);
+        frames_in = a.ring;
+    }
+    stft_body<NFFT, false, true>(smem, d, frames_in, nullptr, a.mel, a.peak, DN_PEAK_NORMALIZE | DN_PRE_WINDOW, b, tid);        // P1-P6
+    __syncthreads();
+    cell_body<kHopThreads / 64, BF16>(smem, cd, a.mel, a.hx, a.diff, a.hx, 3, a.C, b, tid);                                     // P7
+    __syncthreads();
+    // P8-P12: the inverse-mel contraction is the Griffin-Lim prologue (the linear magnitudes stay in LDS)
+    if (!STREAM)
+        gl_body<NFFT, true, false>(smem, d, a.mel, a.diff, reinterpret_cast<const v2f*>(a.init), a.seed, a.sid0, a.peak, a.out, a.n_iter, a.mom, b, tid);
+    else
+        gl_body<NFFT, true, true>(smem, d, a.mel, a.diff, reinterpret_cast<const v2f*>(a.init), a.seed, a.sid0, a.peak, nullptr, a.n_iter, a.mom, b, tid,
+                                  a.ola, a.hop_out, 0);
+}
+
+template <int NFFT, bool STREAM>
+static void launch_frame_n(const DspDev& d, const CellDev& c, const FrameArgs& a, int B, bool bf16, hipStream_t st) {
+    if (bf16) hipLaunchKernelGGL((frame_kernel<NFFT, STREAM, true>), dim3(B), dim3(kHopThreads), 0, st, d, c, a);
+    else hipLaunchKernelGGL((frame_kernel<NFFT, STREAM, false>), dim3(B), dim3(kHopThreads), 0, st, d, c, a);
+}
+
+void launch_frame(const DspDev& d, const CellDev& c, const FrameArgs& a, int B, bool bf16, hipStream_t st) {
+    const bool stream = a.ring != nullptr;
+    if (d.n_fft == 1536) {
+        if (stream) launch_frame_n<1536, true>(d, c, a, B, bf16, st);
+        else launch_frame_n<1536, false>(d, c, a, B, bf16, st);
+    } else {
+        if (stream) launch_frame_n<1024, true>(d, c, a, B, bf16, st);
+        else launch_frame_n<1024, false>(d, c, a, B, bf16, st);
+    }
 }
 
 }  // namespace dn
+
+#ifdef DN_PROBE
+// diagnostic build only: the stamps of the Griffin-Lim workgroup 0 of hop_kernel / frame_kernel
+extern "C" int dn_probe_read_hop(unsigned long long* host48) {
+    return (int)hipMemcpyFromSymbol(host48, HIP_SYMBOL(dn::g_gl_probe), sizeof(dn::g_gl_probe));
+}
+#endif

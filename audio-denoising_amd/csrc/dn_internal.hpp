@@ -39,20 +39,47 @@ void launch_synthesis(const DspDev& d, const float* x, const float* diff, const 
                       const float* scale, float* wave, int B, int n_iter, float momentum, hipStream_t st);
 void launch_cell(const CellDev& c, const float* x, const float* hx_in, float* out, float* hx_out, int B, int T,
                  int C, hipStream_t st);
+// Device-resident control block of a dn_pipe.  Every launch of hop_kernel derives its scratch slot, the Griffin-Lim seed
+// and whether a hop is pending from it, and its last workgroup advances it -- so a launch captured in a hipGraph can
+// be replayed indefinitely (nothing that changes from hop to hop is baked into the kernel arguments).
+struct PipeCtl {
+    unsigned long long pushes;   // launches that carried a front half (streaming: the first n_fft/hop - 1 only fill the ring)
+    unsigned long long frames;   // frames whose front half (P1-P10) has run; frame f uses scratch slot f & 1
+    unsigned int pending;        // 1: the Griffin-Lim of frame frames-1 has not run yet
+    unsigned int done;           // workgroup ticket of the launch in flight (0 between launches)
+};
+
 // Arguments of the software-pipelined hop launch (dn_hop.hip).
 struct HopArgs {
-    // front half: this hop's analysis + model + inverse mel, writing one scratch slot
-    const float* frames; float* hx; float* mel; float* diff; float* peak; float* lin;
-    // back half: the previous hop's Griffin-Lim, reading the other slot
-    const float* gl_lin; const float* gl_peak; const float* gl_init; uint64_t gl_seed, gl_sid0; float* gl_out;
+    PipeCtl* ctl;
+    // scratch slots, each: mel [B][3][M] | residual [B][3][M] | peak [B] | meta [B][8] (u32: has_init, seed lo/hi, stream_id0 lo/hi, -) | lin [B][3][K]
+    float* slot[2];
+    float2* slot_init[2];    // [B][3][K] complex initial phases of the slot's frame (parity mode), or null
+    // front half: this hop's analysis + model + inverse mel, written to slot frames & 1
+    const float* frames; float* hx;
+    const float* init_in;    // this hop's initial phases [B][3][K] complex (copied into the slot), or null = device RNG
+    uint64_t seed, sid0;     // the frame's Griffin-Lim draws from (seed + frame index, sid0 + stream)
+    // back half: the pending hop's Griffin-Lim, read from slot (frames - 1) & 1
+    float* gl_out;
     int n_iter; float mom;
-    int front_B, back_B, C;
+    int front_B, back_B, B, C;
     // streaming mode (pipe-owned per-stream state): the front half first shifts `hop_in` into `ring` and uses the ring
     // as its frame (app3.py:178,226); the back half folds its frame into `ola` and emits `hop_out` (app3.py:219-224)
-    const void* hop_in; float* ring; int in_s16; int prime_only;
+    const void* hop_in; float* ring; int in_s16; int prime;
     float* ola; void* hop_out; int out_s16;
 };
-void launch_hop(const DspDev& d, const CellDev& c, const HopArgs& a, hipStream_t st);
+void launch_hop(const DspDev& d, const CellDev& c, const HopArgs& a, bool bf16, hipStream_t st);
+void launch_ctl_set(PipeCtl* ctl, unsigned long long pushes, unsigned long long frames, unsigned int pending, hipStream_t st);
+
+// The whole hop for one batch in ONE launch, nothing overlapped (dn_process_frame / dn_stream_step).
+struct FrameArgs {
+    const float* frames; float* hx; float* out;
+    float* mel; float* diff; float* peak;        // workspace (diff may be the caller's mel_residual_out)
+    const float* init; uint64_t seed, sid0;
+    int n_iter; float mom; int C;
+    const float* hop_in; float* ring; float* ola; float* hop_out;    // dn_stream_step (ring != null)
+};
+void launch_frame(const DspDev& d, const CellDev& c, const FrameArgs& a, int B, bool bf16, hipStream_t st);
 void launch_cell_bf16(const CellDev& c, const float* x, const float* hx_in, float* out, float* hx_out, int B, int T,
                       int C, hipStream_t st);
 void launch_cell_ex(const CellDev& c, const float* x, const float* hx_in, float* out, float* hx_out, int B, int T,
@@ -61,7 +88,5 @@ void launch_stft_general(const DspDev& d, const float* x, float* spec, float* lo
 void launch_server_rows(const DspDev& d, const float* logmel, const float* model_out, const float* spec_in, float* spec_out, int rows,
                         hipStream_t st);
 void launch_istft_general(const DspDev& d, const float* spec, float* wave, int B, int T, hipStream_t st);
-void launch_stream_shift(int n_fft, const float* hop_in, float* ring, int B, hipStream_t st);
-void launch_stream_ola(int n_fft, const float* y, float* ola, float* hop_out, int B, hipStream_t st);
 
 }  // namespace dn

@@ -92,13 +92,29 @@ class GRUUNet2(nn.Module):
         return torch.cat([v.detach().reshape(-1).to(device="cpu", dtype=torch.float32) for v in self.state_dict().values()])
 
     def _native(self, device: torch.device):
-        tensors = list(self.state_dict(keep_vars=True).values())
+        """The dn_model* for the current weights on `device` (rebuilt when a parameter was replaced or modified)."""
+        return self._native_owner(device).handle
+
+    def _native_owner(self, device: torch.device) -> "_NativeModel":
+        """The object that owns the dn_model*: whoever keeps using the handle across calls (the pipes) holds on to it."""
+        # (dict, name) of every state_dict entry, in state_dict order: reading the live tensors through them costs ~2 us, where
+        # state_dict() itself costs ~40 us -- this runs once per hop on the unpipelined path.  Replaced parameter objects,
+        # .to() and in-place updates (load_state_dict, an optimizer step) all change the key below.
+        slots = self.__dict__.get("_sd_slots")
+        if slots is None:
+            slots = []
+            for _, mod in self.named_modules():
+                slots += [(mod._parameters, n) for n, v in mod._parameters.items() if v is not None]
+                slots += [(mod._buffers, n) for n, v in mod._buffers.items() if v is not None and n not in mod._non_persistent_buffers_set]
+            assert [d[n] is v for (d, n), v in zip(slots, self.state_dict(keep_vars=True).values())].count(False) == 0
+            self.__dict__["_sd_slots"] = slots
+        tensors = [d[n] for d, n in slots]
         key = tuple((t.data_ptr(), t._version) for t in tensors)
         idx = device.index if device.index is not None else torch.cuda.current_device()
         per_model = _NATIVE.setdefault(self, {})
         hit = per_model.get(idx)
         if hit is not None and hit.key == key:
-            return hit.handle
+            return hit
         if not self._supported:
             raise NotImplementedError(
                 "the HIP kernels are built for the architecture of the reference's GRUUNet2 checkpoints "
@@ -109,8 +125,8 @@ class GRUUNet2(nn.Module):
         handle = C.c_void_p()
         with torch.cuda.device(idx):
             lib.check(lib.dn_model_create(C.c_void_p(blob.data_ptr()), blob.numel(), C.byref(cfg), C.byref(handle)))
-        per_model[idx] = _NativeModel(lib, key, handle)     # a replaced entry is destroyed by its finalizer
-        return handle
+        per_model[idx] = _NativeModel(lib, key, handle)     # a replaced entry drops its reference; pipes bound to it keep theirs
+        return per_model[idx]
 
     # ------------------------------------------------------------------ forward
     def forward(self, input, hx=None):

@@ -41,6 +41,12 @@ class Denoiser:
         self._ws = None
         self._calls = 0
 
+    def _flags(self) -> int:
+        """DN_CONV_BF16 when the model asks for bf16 MFMA conv tiles (GRUUNet2.conv_precision, BASELINE config 3)."""
+        if self.model.conv_precision not in ("fp32", "bf16"):
+            raise ValueError("conv_precision must be 'fp32' or 'bf16'")
+        return _lib.DN_CONV_BF16 if self.model.conv_precision == "bf16" else 0
+
     # -- helpers
     def _workspace(self, batch: int) -> torch.Tensor:
         need = self.plan.workspace_bytes(batch)
@@ -88,7 +94,7 @@ class Denoiser:
             st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
             self.lib.check(self.lib.dn_process_frame(model_h, self.plan.handle, frames.data_ptr(), hx_new.data_ptr(), out.data_ptr(),
                                                      None if resid is None else resid.data_ptr(), ia_ptr, seed, stream_id0,
-                                                     self.n_iter, self.momentum, ws.data_ptr(), B, st))
+                                                     self.n_iter, self.momentum, ws.data_ptr(), B, self._flags(), st))
         return (out, hx_new, resid) if return_residual else (out, hx_new)
 
     def process_frame_(self, frames: torch.Tensor, hx: torch.Tensor, out: torch.Tensor, seed: int = 0, stream_id0: int = 0) -> None:
@@ -100,7 +106,7 @@ class Denoiser:
         with torch.cuda.device(self.device):          # the launch goes to the CURRENT device: make it the denoiser's
             st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
             self.lib.check(self.lib.dn_process_frame(model_h, self.plan.handle, frames.data_ptr(), hx.data_ptr(), out.data_ptr(), None, None,
-                                                     seed, stream_id0, self.n_iter, self.momentum, ws.data_ptr(), B, st))
+                                                     seed, stream_id0, self.n_iter, self.momentum, ws.data_ptr(), B, self._flags(), st))
 
 
 class ServerDenoiser:
@@ -147,89 +153,139 @@ class ServerDenoiser:
         return wave, hx1
 
 
-class HopPipeline:
-    """Software-pipelined hops (``dn_pipe_*``): one launch per hop carries hop n's Griffin-Lim workgroups next to
-    hop n+1's analysis + GRUUNet2 + inverse-mel workgroups; ``hx`` is the only dependency between hops.
-    ``submit`` enqueues one hop for the whole batch on the current stream; the output of a hop is complete (in
-    stream order) after the next ``submit`` or ``flush``.  ``frames``/``out``/``hx``/``init_angles`` must not be
-    touched until then."""
+class _Pipe:
+    """Common part of the two front ends of ``dn_pipe``: owns the native pipe, keeps it bound to the model's CURRENT
+    weights (the pipe itself holds a reference on the dn_model it launches with, so reloading weights between two hops
+    can never leave it with freed device memory: ``_bind`` rebinds it to the new handle before the next launch)."""
 
-    def __init__(self, denoiser: "Denoiser", batch: int):
+    def __init__(self, denoiser: "Denoiser", batch: int, streaming: bool):
         import weakref
         self.dn, self.batch = denoiser, batch
         self.lib = denoiser.lib
         handle = C.c_void_p()
-        self._model_handle = denoiser.model._native(denoiser.device)
+        self._owner = denoiser.model._native_owner(denoiser.device)      # keeps the dn_model alive on the Python side too
+        self._flags = denoiser._flags()
+        create = self.lib.dn_pipe_stream_create if streaming else self.lib.dn_pipe_create
         with torch.cuda.device(denoiser.device):
-            self.lib.check(self.lib.dn_pipe_create(self._model_handle, denoiser.plan.handle, batch, C.byref(handle)))
+            self.lib.check(create(self._owner.handle, denoiser.plan.handle, batch, self._flags, C.byref(handle)))
         self.handle = handle
-        self._keep = (None, None)
         self._fin = weakref.finalize(self, self.lib.dn_pipe_destroy, handle)
 
+    def _bind(self) -> None:
+        """Follow the model: weights reloaded / moved / updated since the last hop -> rebind the pipe (one C call)."""
+        owner = self.dn.model._native_owner(self.dn.device)
+        if owner is not self._owner:
+            self.lib.check(self.lib.dn_pipe_set_model(self.handle, owner.handle))
+            self._owner = owner
+        if self.dn._flags() != self._flags:
+            raise RuntimeError("conv_precision changed after the pipeline was created; create a new pipeline")
+
+    def counters(self):
+        """(pushes, frames, pending) of the device-resident control block.  Synchronises the current stream."""
+        a, b, c = C.c_uint64(), C.c_uint64(), C.c_int32()
+        with torch.cuda.device(self.dn.device):
+            st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            self.lib.check(self.lib.dn_pipe_get_counters(self.handle, C.byref(a), C.byref(b), C.byref(c), st))
+        return a.value, b.value, bool(c.value)
+
+
+class HopPipeline(_Pipe):
+    """Software-pipelined hops (``dn_pipe_*``): one launch per hop carries hop n's Griffin-Lim workgroups next to
+    hop n+1's analysis + GRUUNet2 + inverse-mel workgroups; ``hx`` is the only dependency between hops.
+    ``submit`` enqueues one hop for the whole batch on the current stream; the output of a hop is complete (in
+    stream order) after the next ``submit`` or ``flush``.  ``frames``/``out``/``hx`` must not be touched until then.
+    The Griffin-Lim of the f-th submitted hop draws from ``seed + f``.  A ``submit`` captured in a hipGraph can be
+    replayed: slot parity, pending flag and frame index live on the device."""
+
+    def __init__(self, denoiser: "Denoiser", batch: int):
+        super().__init__(denoiser, batch, streaming=False)
+
     def submit(self, frames: torch.Tensor, hx: torch.Tensor, out: torch.Tensor, seed: int = 0, stream_id0: int = 0,
-               init_angles: torch.Tensor | None = None) -> None:
+               init_angles: torch.Tensor | None = None, check_weights: bool = True) -> None:
         d = self.dn
+        if check_weights:
+            self._bind()
         keep, ia_ptr = d._angles_ptr(init_angles, self.batch)
-        self._keep = (self._keep[1], keep)      # this hop's and the previous hop's phases stay alive
         with torch.cuda.device(d.device):
             st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
             self.lib.check(self.lib.dn_pipe_submit(self.handle, frames.data_ptr(), hx.data_ptr(), out.data_ptr(), ia_ptr, seed, stream_id0,
                                                    d.n_iter, d.momentum, st))
+            if keep is not None and not torch.cuda.is_current_stream_capturing():
+                keep.record_stream(torch.cuda.current_stream())     # the launch copies the phases into its scratch slot
 
     def flush(self) -> None:
         with torch.cuda.device(self.dn.device):
             st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-            self.lib.check(self.lib.dn_pipe_flush(self.handle, st))
+            self.lib.check(self.lib.dn_pipe_flush(self.handle, self.dn.n_iter, self.dn.momentum, st))
 
 
-class PipelinedStream:
+class PipelinedStream(_Pipe):
     """B concurrent streams, state (ring, overlap-add line, hx) owned by the native pipe, ONE launch per hop
     (``dn_pipe_stream_*``; BASELINE config 5).  ``push(hop)`` takes ``(B, hop_length)`` new samples (float32, or int16
     PCM) and returns ``(B, hop_length)`` output samples in the same format.  Hops are software-pipelined, so the
     samples the reference emits while processing frame f come out one push later (zeros until then);
-    ``flush()`` returns the last pending hop."""
+    ``flush()`` returns the last pending hop.  Frame f's Griffin-Lim draws from ``seed + f`` (as ``DenoiserStream``).
+    ``push_`` writes into a caller-provided tensor and allocates nothing: captured in a hipGraph it is the replayable
+    steady-state step (``graph_step``)."""
 
     def __init__(self, denoiser: "Denoiser", batch: int, stream_id0: int = 0, seed: int = 0):
-        import weakref
-        self.dn, self.batch, self.stream_id0, self.seed = denoiser, batch, stream_id0, seed
-        self.lib = denoiser.lib
-        handle = C.c_void_p()
-        self._model_handle = denoiser.model._native(denoiser.device)
-        with torch.cuda.device(denoiser.device):
-            self.lib.check(self.lib.dn_pipe_stream_create(self._model_handle, denoiser.plan.handle, batch, C.byref(handle)))
-        self.handle = handle
-        self._keep = (None, None)
-        self.pushes = 0
-        self._fin = weakref.finalize(self, self.lib.dn_pipe_destroy, handle)
+        super().__init__(denoiser, batch, streaming=True)
+        self.stream_id0, self.seed = stream_id0, seed
 
     def _out(self, like_s16: bool) -> torch.Tensor:
         return torch.empty(self.batch, self.dn.hop, dtype=torch.int16 if like_s16 else torch.float32, device=self.dn.device)
 
-    def push(self, hop: torch.Tensor, init_angles: torch.Tensor | None = None) -> torch.Tensor:
+    def push_(self, hop: torch.Tensor, out: torch.Tensor, init_angles: torch.Tensor | None = None, check_weights: bool = True) -> None:
+        """Allocation-free push: ``out`` (same shape/dtype family as ``hop``) receives the emitted samples."""
         d = self.dn
-        if hop.device != d.device or tuple(hop.shape) != (self.batch, d.hop) or hop.dtype not in (torch.float32, torch.int16) \
-                or not hop.is_contiguous():
-            raise ValueError(f"hop must be contiguous float32 or int16 of shape {(self.batch, d.hop)} on {d.device}")
-        s16 = hop.dtype == torch.int16
-        out = self._out(s16)
+        for t, name in ((hop, "hop"), (out, "out")):
+            if t.device != d.device or tuple(t.shape) != (self.batch, d.hop) or t.dtype not in (torch.float32, torch.int16) \
+                    or not t.is_contiguous():
+                raise ValueError(f"{name} must be contiguous float32 or int16 of shape {(self.batch, d.hop)} on {d.device}")
+        if check_weights:
+            self._bind()
         keep, ia_ptr = d._angles_ptr(init_angles, self.batch)
-        self._keep = (self._keep[1], (keep, hop))
         with torch.cuda.device(d.device):
-            st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-            self.lib.check(self.lib.dn_pipe_stream_push(self.handle, hop.data_ptr(), int(s16), out.data_ptr(), int(s16), ia_ptr,
-                                                        self.seed + self.pushes, self.stream_id0, d.n_iter, d.momentum, st))
-        self.pushes += 1
+            cur = torch.cuda.current_stream()
+            self.lib.check(self.lib.dn_pipe_stream_push(self.handle, hop.data_ptr(), int(hop.dtype == torch.int16), out.data_ptr(),
+                                                        int(out.dtype == torch.int16), ia_ptr, self.seed, self.stream_id0, d.n_iter,
+                                                        d.momentum, C.c_void_p(cur.cuda_stream)))
+            if keep is not None and not torch.cuda.is_current_stream_capturing():
+                keep.record_stream(cur)
+
+    def push(self, hop: torch.Tensor, init_angles: torch.Tensor | None = None) -> torch.Tensor:
+        out = self._out(hop.dtype == torch.int16)
+        self.push_(hop, out, init_angles)
+        hop.record_stream(torch.cuda.current_stream(self.dn.device))
         return out
+
+    def graph_step(self, hop: torch.Tensor, out: torch.Tensor, init_angles: torch.Tensor | None = None) -> "torch.cuda.CUDAGraph":
+        """Capture ONE push into a hipGraph (BASELINE config 5: the hipGraph-captured step).  Replaying it is a push of
+        whatever ``hop`` (and ``init_angles``, parity mode) hold at that moment into ``out``; it can be replayed
+        indefinitely and mixed with eager pushes."""
+        self._bind()
+        if init_angles is not None:
+            # the slot buffers for injected phases are allocated by the first parity-mode launch: do that outside the capture
+            self._warm_parity()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.push_(hop, out, init_angles, check_weights=False)
+        return g
+
+    def _warm_parity(self) -> None:
+        with torch.cuda.device(self.dn.device):
+            self.lib.check(self.lib.dn_pipe_reserve_parity(self.handle))
 
     def flush(self, s16: bool = False) -> torch.Tensor:
         out = self._out(s16)
         with torch.cuda.device(self.dn.device):
             st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-            self.lib.check(self.lib.dn_pipe_stream_flush(self.handle, out.data_ptr(), int(s16), st))
+            self.lib.check(self.lib.dn_pipe_stream_flush(self.handle, out.data_ptr(), int(s16), self.dn.n_iter, self.dn.momentum, st))
         return out
 
     def state(self):
-        """Snapshot (ring, ola, hx) of the pipe-owned stream state (checkpointing live streams)."""
+        """Snapshot (ring, ola, hx, frames) of the pipe-owned stream state (checkpointing live streams; call after
+        ``flush()``).  ``frames`` is the number of frames processed so far: it keys the Griffin-Lim seed sequence."""
         d = self.dn
         ring = torch.empty(self.batch, d.n_fft, dtype=torch.float32, device=d.device)
         ola = torch.empty_like(ring)
@@ -237,17 +293,16 @@ class PipelinedStream:
         with torch.cuda.device(d.device):
             st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
             self.lib.check(self.lib.dn_pipe_stream_get_state(self.handle, ring.data_ptr(), ola.data_ptr(), hx.data_ptr(), st))
-        return ring, ola, hx
+        return ring, ola, hx, self.counters()[1]
 
-    def load_state(self, ring: torch.Tensor, ola: torch.Tensor, hx: torch.Tensor) -> None:
-        """Resume streams from a snapshot taken with ``state()`` (after ``flush()``)."""
+    def load_state(self, ring: torch.Tensor, ola: torch.Tensor, hx: torch.Tensor, frames: int = 0) -> None:
+        """Resume streams from a snapshot taken with ``state()``: the next frame is frame ``frames`` of the seed sequence."""
         for t in (ring, ola, hx):
             if t.device != self.dn.device or t.dtype != torch.float32 or not t.is_contiguous():
                 raise ValueError("state tensors must be contiguous float32 on the denoiser's device")
         with torch.cuda.device(self.dn.device):
             st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-            self.lib.check(self.lib.dn_pipe_stream_set_state(self.handle, ring.data_ptr(), ola.data_ptr(), hx.data_ptr(), st))
-        self.pushes = max(self.pushes, self.dn.n_fft // self.dn.hop - 1)
+            self.lib.check(self.lib.dn_pipe_stream_set_state(self.handle, ring.data_ptr(), ola.data_ptr(), hx.data_ptr(), int(frames), st))
 
 
 class DenoiserStream:
@@ -255,7 +310,8 @@ class DenoiserStream:
 
     ``push(chunk)`` mirrors one ``recv`` call of the reference for every stream at once
     (app3.py:174-226): append samples, run one hop per ``hop_length`` new samples once ``n_fft``
-    samples are buffered, return the emitted output samples."""
+    samples are buffered, return the emitted output samples.  No added latency (one launch per hop,
+    ``dn_stream_step``); frame f's Griffin-Lim draws from ``seed + f``."""
 
     def __init__(self, denoiser: Denoiser, batch: int, stream_id0: int = 0, seed: int = 0):
         self.dn, self.batch, self.stream_id0, self.seed = denoiser, batch, stream_id0, seed
@@ -293,7 +349,7 @@ class DenoiserStream:
                 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
                 d.lib.check(d.lib.dn_stream_step(model_h, d.plan.handle, hop_in.data_ptr(), self.ring.data_ptr(), self.ola.data_ptr(),
                                                  self.hx.data_ptr(), hop_out.data_ptr(), ia_ptr, self.seed + self.hops, self.stream_id0,
-                                                 d.n_iter, d.momentum, ws.data_ptr(), self.batch, st))
+                                                 d.n_iter, d.momentum, ws.data_ptr(), self.batch, d._flags(), st))
             outs.append(hop_out)
             self.hops += 1
             i += 1

@@ -4,21 +4,30 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (a torchrun child
+process, started before this process touches the GPU) and fails loudly when the node has fewer than N GPUs.
+
 A "step" is one pass of the whole per-hop path (P1..P12 of SURVEY.md section 8a: peak-normalise, Hann,
 3-column STFT, mel, log1p, GRUUNet2 x3 steps, residual, expm1, inverse mel, 32-iteration Griffin-Lim,
 `* peak`) over one batch of 256 synthetic frames per GPU, inputs resident in HBM, hidden state carried
 from step to step.  Streams are independent, so N GPUs run N x 256 streams with no data-path collective
-(weak scaling); the only collectives are the barriers and the MAX of the elapsed time.
+(weak scaling); the only collectives of the headline are the barriers and the MAX of the elapsed time.  With N > 1 the
+same run also times the ingress-inclusive variant SURVEY.md section 8e asks for: rank 0 holds all N x 256 frames, every
+step scatters them to the ranks and gathers the denoised frames back (RCCL grouped send/recv over xGMI, issued on a
+second HIP stream and double-buffered so hop i+1's ingress and hop i-1's egress overlap hop i's kernels); it is
+reported in `ingress_variant`, never as `value`.
 
 Besides the contract fields the JSON line carries
   roofline     -- the dominant kernel (hop_kernel: one launch = one hop of the batch): algorithmic FLOPs per launch /
                   its average launch duration measured with HIP events in this process, against the fp32 compute peak;
   cpu_baseline -- the CPU oracle (the reference's op sequence restated on torch-CPU, oracle/pipeline_ref.py)
-                  timed on this host's cores on a bounded sample of the same workload (rank 0, N = 1 only).
+                  timed on this host's cores on a bounded sample of the same workload (rank 0, N = 1 only): all the
+                  cores the process may use, and one thread.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -36,19 +45,20 @@ GL_ITERS = 32
 FLOP_PER_RFFT = 2.5 * N_FFT * 10
 GL_FFTS = GL_ITERS * 6 + 3
 GL_FLOP_PER_FRAME = GL_FFTS * FLOP_PER_RFFT + 246240              # 4.992 MFLOP of FFTs + the fused inverse-mel contraction
-TOTAL_FLOP_PER_FRAME = 198 * FLOP_PER_RFFT + 2 * 246240 + 939150  # 6.50 MFLOP
+CONV_FLOP_PER_FRAME = 939150                                      # 2 x 469,575 MACs: the MFMA-eligible UNet convs
+TOTAL_FLOP_PER_FRAME = 198 * FLOP_PER_RFFT + 2 * 246240 + CONV_FLOP_PER_FRAME  # 6.50 MFLOP
 HBM_BYTES_PER_FRAME = 4 * N_FFT + 4 * N_FFT + 2 * 4 * 17 * 5       # 8,872 B compulsory
-GL_HBM_BYTES_PER_FRAME = 2 * 4 * 3 * N_MELS + 4 * N_FFT + 4        # kernel-level: model input + residual in, waveform out, peak
 PEAK_FP32_TFLOPS = 157.3                                          # MI355X_MICROARCH.md: vector == matrix fp32 peak
+PEAK_BF16_TFLOPS = 2500.0                                         # dense bf16 MFMA
 PEAK_HBM_GBS = 8000.0
-
+METRIC = "denoised audio frames/sec (32 ms, 16 kHz, hop 512) at batch 256; 1/2/4/8 GPU"
 
 # parameter presets: S = BASELINE.json's synthetic config (the metric); R1 = the reference app's own (app3.py:13-33);
 # R2 = server.py:166-170.  Only S is the headline; the others are reported by `--preset` for DESIGN.md.
 PRESETS = {"S": (16000, 1024, 512, 80, "dari_tult"), "R1": (48000, 1536, 768, 64, "dari_tult2"), "R2": (48000, 1024, 512, 64, "dari_tult")}
 
 
-def build_denoiser(dev, preset="S"):
+def build_denoiser(dev, preset="S", conv="fp32"):
     from audio_denoising_amd.gruunet2 import GRUUNet2
     from audio_denoising_amd.pipeline import Denoiser
     sr, n_fft, hop, n_mels, ckpt = PRESETS[preset]
@@ -62,12 +72,13 @@ def build_denoiser(dev, preset="S"):
         off += n
     model.load_state_dict(sd)
     model.eval().to(dev)
+    model.conv_precision = conv
     return Denoiser(model, sr, n_fft, hop, n_mels, n_iter=GL_ITERS)
 
 
 def staged_kernel_times(dn, frames, hx, steps):
-    """The same three launches dn_process_frame makes, issued one ABI call each with HIP events in between
-    (torch.cuda.Event on the stream the kernels are launched on).  Returns mean ms per kernel."""
+    """The stages of the hop as separate launches (dn_stft_mel_log1p, dn_cell_forward[_bf16], dn_synthesis), one ABI call each with HIP
+    events in between (torch.cuda.Event on the stream the kernels are launched on).  Returns mean ms per kernel."""
     import ctypes as C
     from audio_denoising_amd import _lib
     lib, plan, dev = dn.lib, dn.plan, dn.device
@@ -78,6 +89,7 @@ def staged_kernel_times(dn, frames, hx, steps):
     out = torch.empty_like(frames)
     model_h = dn.model._native(dev)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    cell = lib.dn_cell_forward_bf16 if dn.model.conv_precision == "bf16" else lib.dn_cell_forward
     names = ["stft_mel_log1p", "cell", "synthesis"]
     acc = dict.fromkeys(names, 0.0)
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(steps)]
@@ -87,7 +99,7 @@ def staged_kernel_times(dn, frames, hx, steps):
         lib.check(lib.dn_stft_mel_log1p(plan.handle, frames.data_ptr(), mel.data_ptr(), peak.data_ptr(), B,
                                         _lib.DN_PEAK_NORMALIZE | _lib.DN_PRE_WINDOW, st))
         e[1].record()
-        lib.check(lib.dn_cell_forward(model_h, mel.data_ptr(), hx.data_ptr(), diff.data_ptr(), hx.data_ptr(), B, 3, N_MELS, N_MELS // 16, st))
+        lib.check(cell(model_h, mel.data_ptr(), hx.data_ptr(), diff.data_ptr(), hx.data_ptr(), B, 3, N_MELS, N_MELS // 16, st))
         e[2].record()
         lib.check(lib.dn_synthesis(plan.handle, mel.data_ptr(), diff.data_ptr(), None, 7 + s, 0, peak.data_ptr(), out.data_ptr(), B, GL_ITERS, 0.99, st))
         e[3].record()
@@ -98,26 +110,41 @@ def staged_kernel_times(dn, frames, hx, steps):
     return {n: acc[n] / steps for n in names}
 
 
-def cpu_baseline(budget_s=20.0):
-    """The reference's op sequence on the host CPU (oracle, kind 'port'), batch 256 and batch 1."""
+def usable_cores():
+    """Cores this process may really use: the scheduler affinity, capped by the cgroup CPU quota when there is one
+    (a GPU box hands a one-GPU job a share of a much larger host; threads beyond the quota only thrash)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline(budget_s=24.0):
+    """The reference's op sequence on the host CPU (oracle, kind 'port'): batch 256 on every core this process may use,
+    batch 256 on ONE thread, and batch 1 (how the app really runs) -- a bounded sample of the same synthetic workload."""
     from oracle import dsp_ref, model_ref, pipeline_ref
     p = pipeline_ref.PARAMS_S
     sd = model_ref.unflatten_weights(np.fromfile(os.path.join(REPO, "tests", "golden", "weights_dari_tult.bin"), dtype=np.float32))
     fb = dsp_ref.melscale_fbanks(p.n_stft, p.n_mels, p.sample_rate)
-    # the GPU box gives one-GPU jobs a 16-core share of a much larger host: size the thread pool to the share
-    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("DN_CPU_THREADS", "16")))
-    torch.set_num_threads(cores)
+    affinity = len(os.sched_getaffinity(0))
+    cores = int(os.environ.get("DN_CPU_THREADS", str(usable_cores())))  # every core this process may use (affinity, cgroup quota)
     res = {}
-    for B, share in ((BATCH, 0.75), (1, 0.25)):
+    for tag, B, threads, share in (("all", BATCH, cores, 0.45), ("one", BATCH, 1, 0.40), ("b1", 1, cores, 0.15)):
+        torch.set_num_threads(threads)
         g = torch.Generator().manual_seed(1234)
         frames = 0.1 * torch.randn(B, p.n_fft, generator=g)
         hx = torch.zeros(B, 17, 5)
         gen = torch.Generator().manual_seed(4321)
         with torch.no_grad():
             tw = time.perf_counter()
-            r = pipeline_ref.process_frame(sd, frames, hx, p, fb, generator=gen)     # warm-up
-            hx = r["hx"]
-            print(f"[bench] cpu baseline B={B}: warm-up step {time.perf_counter() - tw:.2f} s on {cores} threads", file=sys.stderr, flush=True)
+            if tag != "one":
+                r = pipeline_ref.process_frame(sd, frames, hx, p, fb, generator=gen)     # warm-up
+                hx = r["hx"]
+            print(f"[bench] cpu baseline {tag}: B={B}, {threads} threads, warm-up {time.perf_counter() - tw:.2f} s", file=sys.stderr, flush=True)
             n, t0 = 0, time.perf_counter()
             while True:
                 r = pipeline_ref.process_frame(sd, frames, hx, p, fb, generator=gen)
@@ -126,12 +153,16 @@ def cpu_baseline(budget_s=20.0):
                 el = time.perf_counter() - t0
                 if el >= budget_s * share or n >= 200:
                     break
-        res[B] = (B * n / el, n, el)
-    v, n, el = res[BATCH]
+        res[tag] = (B * n / el, n, el)
+    torch.set_num_threads(cores)
+    v, n, el = res["all"]
     return {"value": round(v, 1), "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"{n} steps of batch {BATCH} ({el:.1f} s) of the same synthetic workload through oracle/pipeline_ref.process_frame "
                       f"(torch-CPU stft/matmul/conv1d/lstsq(gels)/32-iter Griffin-Lim, {cores} threads)",
-            "batch1_value": round(res[1][0], 1)}
+            "host": {"sched_getaffinity": affinity, "os_cpu_count": os.cpu_count(), "usable_cores": usable_cores()},
+            "one_thread_value": round(res["one"][0], 1),
+            "one_thread_sample": f"{res['one'][1]} steps of batch {BATCH} ({res['one'][2]:.1f} s), torch.set_num_threads(1)",
+            "batch1_value": round(res["b1"][0], 1)}
 
 
 def side_measurement(args, dn, B, dev):
@@ -140,12 +171,22 @@ def side_measurement(args, dn, B, dev):
     g = torch.Generator().manual_seed(1234)
     out = torch.empty(B, dn.n_fft, device=dev)
     hx = dn.init_hx(B)
+    mode = "frames"
     if args.stream:
         ps = PipelinedStream(dn, B)
         hop = (0.1 * torch.randn(B, dn.hop, generator=g)).to(dev)
+        hop_out = torch.empty_like(hop)
+        mode = "stream"
+        if args.graph:
+            # BASELINE config 5: ONE hipGraph-captured push replayed per hop (slot parity / seed / pending live on the device)
+            graph = ps.graph_step(hop, hop_out)
+            mode = "stream+hipGraph"
 
-        def step(i):
-            ps.push(hop)
+            def step(i):
+                graph.replay()
+        else:
+            def step(i):
+                ps.push_(hop, hop_out, check_weights=False)
         fin = ps.flush
     elif args.pcie:
         # the boundary hands over HOST buffers: every hop moves its frames up and its result down over PCIe (pinned,
@@ -155,11 +196,12 @@ def side_measurement(args, dn, B, dev):
         dframes = [torch.empty(B, dn.n_fft, device=dev) for _ in range(2)]
         douts = [torch.empty(B, dn.n_fft, device=dev) for _ in range(2)]
         pipe = HopPipeline(dn, B)
+        mode = "frames+pcie"
 
         def step(i):
             s = i & 1
             dframes[s].copy_(host_in, non_blocking=True)
-            pipe.submit(dframes[s], hx, douts[s], seed=1000 + i)          # also completes hop i-1 (its Griffin-Lim blocks)
+            pipe.submit(dframes[s], hx, douts[s], seed=1000)              # also completes hop i-1 (its Griffin-Lim blocks)
             host_out[s ^ 1].copy_(douts[s ^ 1], non_blocking=True)
         fin = pipe.flush
     else:
@@ -167,7 +209,7 @@ def side_measurement(args, dn, B, dev):
         pipe = HopPipeline(dn, B)
 
         def step(i):
-            pipe.submit(frames, hx, out, seed=1000 + i)
+            pipe.submit(frames, hx, out, seed=1000, check_weights=False)
         fin = pipe.flush
     t_pre = time.perf_counter()
     while time.perf_counter() - t_pre < 0.5:
@@ -183,10 +225,123 @@ def side_measurement(args, dn, B, dev):
     fin()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    print(json.dumps({"metric": "frames/s (side measurement, not the headline)", "preset": args.preset, "mode": "stream" if args.stream else ("frames+pcie" if args.pcie else "frames"),
+    print(json.dumps({"metric": "frames/s (side measurement, not the headline)", "preset": args.preset, "mode": mode, "conv": args.conv,
                       "value": round(B * args.steps / el, 1), "unit": "frames/s", "streams": B, "ms_per_step": round(1e3 * el / args.steps, 4),
                       "n_fft": dn.n_fft, "hop": dn.hop, "n_mels": dn.n_mels, "sample_rate": dn.sample_rate,
                       "realtime_streams_per_gpu": int(B * args.steps / el / (dn.sample_rate / dn.hop))}), flush=True)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks as a child torchrun job.  Nothing in this process has
+    initialised the GPU yet (device_count() does not), and the ranks are fresh processes -- never an exec of this one."""
+    backend = os.environ.get("DN_DIST_BACKEND", "nccl")
+    n_dev = torch.cuda.device_count()
+    rehearsal = os.environ.get("DN_BENCH_REHEARSAL") == "1" and backend == "gloo"
+    if n_dev < args.gpus and not rehearsal and not (backend == "gloo" and os.environ.get("DN_ALLOW_SHARED_GPU") == "1"):
+        raise SystemExit(f"bench.py --gpus {args.gpus}: this node exposes {n_dev} GPU(s); one rank per GPU is required "
+                         f"(a rehearsal of the rank plumbing on fewer GPUs needs DN_DIST_BACKEND=gloo DN_ALLOW_SHARED_GPU=1)")
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] --gpus {args.gpus} without a launcher: starting {args.gpus} ranks ({' '.join(cmd[1:8])} ...)", file=sys.stderr, flush=True)
+    raise SystemExit(subprocess.run(cmd).returncode)
+
+
+class Rehearsal:
+    """Stand-in for the hop when rehearsing the RANK PLUMBING on CPU-only ranks (DN_BENCH_REHEARSAL=1, gloo; tests/test_bench_ranks.py):
+    `out = 2 * frames`, nothing else.  It exercises self-launch, sharding, barriers, the MAX reduction, the double-buffered
+    scatter/gather loop and the JSON fields -- never a kernel, and its line says so (`data: rehearsal`)."""
+
+    class _P:
+        def __init__(self): self.done = []
+        def submit(self, frames, hx, out, **kw): out.copy_(frames * 2.0)
+        def flush(self): pass
+
+    def __init__(self): self.device, self.n_fft = torch.device("cpu"), N_FFT
+    def init_hx(self, B): return torch.zeros(B, 17, 5)
+    def pipe(self, B): return Rehearsal._P()
+    def process_frame_(self, frames, hx, out, **kw): out.copy_(frames * 2.0)
+
+
+def ingress_variant(dn, pipe, B, world, rank, dev, lo, steps, warmup, dist, backend, fence, on_gpu):
+    """Every step: scatter the N x 256 frames rank 0 holds -> hop -> gather the denoised frames on rank 0.
+    Transfers are issued on a second HIP stream, double-buffered: while hop i computes, hop i+1's frames arrive and hop
+    i-1's result leaves (the pipelined hop completes frame i-1 during launch i)."""
+    from audio_denoising_amd.shard import gather_rows, scatter_rows
+    total = B * world
+    cdev = dev if on_gpu else torch.device("cpu")
+    g = torch.Generator().manual_seed(99)
+    big_in = (0.1 * torch.randn(total, N_FFT, generator=g)).to(cdev) if rank == 0 else None
+    big_out = torch.zeros(total, N_FFT, device=cdev) if rank == 0 else None
+    in_buf = [torch.empty(B, N_FFT, device=cdev) for _ in range(2)]
+    out_buf = [torch.zeros(B, N_FFT, device=cdev) for _ in range(2)]
+    hx = dn.init_hx(B)
+    if on_gpu:
+        comm = torch.cuda.Stream(device=dev)
+        cur = torch.cuda.current_stream(dev)
+        ev_in = [torch.cuda.Event() for _ in range(2)]
+        ev_hop = [torch.cuda.Event() for _ in range(2)]
+        ev_gth = [torch.cuda.Event() for _ in range(2)]
+
+    def scatter(i):
+        scatter_rows(big_in, total, (N_FFT,), torch.float32, cdev, out=in_buf[i & 1])
+
+    def gather(i):
+        gather_rows(out_buf[i & 1], total, out=big_out)
+
+    def run(n):
+        if on_gpu:
+            with torch.cuda.stream(comm):
+                scatter(0)
+                ev_in[0].record(comm)
+            for i in range(n):
+                s = i & 1
+                cur.wait_event(ev_in[s])
+                if i >= 3:
+                    cur.wait_event(ev_gth[s ^ 1])                    # launch i rewrites out_buf[(i-1)&1]: hop i-3's egress has left it
+                pipe.submit(in_buf[s], hx, out_buf[s], seed=3000, stream_id0=lo, check_weights=False)    # launch i: front of hop i, Griffin-Lim of hop i-1
+                ev_hop[s].record(cur)
+                with torch.cuda.stream(comm):
+                    if i + 1 < n:
+                        if i >= 1:
+                            comm.wait_event(ev_hop[s ^ 1])          # launch i-1 has read in_buf[(i+1)&1] (its front half is done)
+                        scatter(i + 1)                               # overlaps launch i
+                        ev_in[s ^ 1].record(comm)
+                    if i >= 1:
+                        comm.wait_event(ev_hop[s])                   # launch i completed hop i-1 into out_buf[(i-1)&1]
+                        gather(i - 1)                                # overlaps launch i+1
+                        ev_gth[s ^ 1].record(comm)
+            pipe.flush()
+            ev_hop[0].record(cur)
+            with torch.cuda.stream(comm):
+                comm.wait_event(ev_hop[0])
+                gather(n - 1)
+            cur.wait_stream(comm)
+        else:
+            for i in range(n):
+                scatter(i)
+                pipe.submit(in_buf[i & 1], hx, out_buf[i & 1], seed=3000, stream_id0=lo)
+                gather(i)
+    run(max(2, warmup))
+    fence()
+    t0 = time.perf_counter()
+    run(steps)
+    fence()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    ok = True
+    if rank == 0:
+        ok = bool(torch.isfinite(big_out).all()) and float(big_out.abs().max()) > 0.0
+    return {"ingress": "scatter_gather", "value": round(total * steps / el, 1), "unit": "frames/s", "ms_per_step": round(1e3 * el / steps, 4),
+            "bytes_per_step_each_way": total * N_FFT * 4, "backend": backend, "overlap": "second HIP stream, double-buffered" if on_gpu else "none (host rehearsal)",
+            "root_output_finite": ok}
 
 
 def main():
@@ -196,67 +351,91 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=BATCH, help="streams per GPU (the metric is quoted at 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--serial", action="store_true", help="one hop at a time, 3 launches (dn_process_frame) instead of the software-pipelined hop")
+    ap.add_argument("--serial", action="store_true", help="one hop at a time, nothing overlapped (dn_process_frame: no hop of added latency) instead of the software-pipelined hop")
     ap.add_argument("--preset", choices=sorted(PRESETS), default="S", help="S = the metric's config; R1/R2 = the reference's own parameters (extra measurements)")
+    ap.add_argument("--conv", choices=["fp32", "bf16"], default="fp32", help="bf16 = BASELINE config 3: UNet convs on bf16 MFMA tiles (restated tolerance); side measurement")
     ap.add_argument("--pcie", action="store_true", help="side measurement: frames arrive in pinned host memory and results return to it every hop")
     ap.add_argument("--stream", action="store_true", help="streaming mode (BASELINE config 5): pipe-owned ring/overlap-add/hx state, one hop of new samples per step")
+    ap.add_argument("--graph", action="store_true", help="with --stream: replay ONE hipGraph-captured push per step")
     args = ap.parse_args()
 
+    rehearsal = os.environ.get("DN_BENCH_REHEARSAL") == "1"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the hop path has no CPU fallback")
-    n_dev = torch.cuda.device_count()
-    dev = torch.device("cuda", local % n_dev)          # one rank per GPU; (rehearsals on a 1-GPU box share cuda:0)
-    torch.cuda.set_device(dev)
-    dist = None
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     backend = os.environ.get("DN_DIST_BACKEND", "nccl")   # "nccl" = RCCL over xGMI; "gloo" only to rehearse the rank plumbing
+    on_gpu = not rehearsal
+    if on_gpu and not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hop path has no CPU fallback")
+    dev = None
+    if on_gpu:
+        n_dev = torch.cuda.device_count()
+        if world > n_dev and not (backend == "gloo" and os.environ.get("DN_ALLOW_SHARED_GPU") == "1"):
+            raise SystemExit(f"{world} ranks but {n_dev} GPU(s): one rank per GPU is required")
+        dev = torch.device("cuda", local % n_dev)
+        torch.cuda.set_device(dev)
+    dist = None
+    ranks_seen = 1
     if world > 1:
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+        t = torch.ones(1, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t)
+        ranks_seen = int(t.item())
+        if ranks_seen != args.gpus:
+            raise SystemExit(f"the {backend} process group sees {ranks_seen} ranks, --gpus asked for {args.gpus}")
 
     from audio_denoising_amd.shard import shard_range
-    dn = build_denoiser(dev, args.preset)
     B = args.batch
-    if args.preset != "S" or args.stream or args.pcie:
+    dn = Rehearsal() if rehearsal else build_denoiser(dev, args.preset, args.conv)
+    if on_gpu and (args.preset != "S" or args.stream or args.pcie):
         return side_measurement(args, dn, B, dev)
     lo, hi = shard_range(B * world, world, rank)          # this rank's global stream ids
     g = torch.Generator().manual_seed(1234 + rank)
-    frames = (0.1 * torch.randn(B, N_FFT, generator=g)).to(dev)
+    frames = (0.1 * torch.randn(B, N_FFT, generator=g)).to(dev if on_gpu else "cpu")
     hx = dn.init_hx(B)
     out = torch.empty_like(frames)
 
     # Product configuration for throughput: software-pipelined hops (dn_pipe_*): ONE launch per hop whose workgroups are
     # hop n's Griffin-Lim next to hop n+1's analysis + model + inverse mel; hx is the only inter-hop dependency.
-    from audio_denoising_amd.pipeline import HopPipeline
-    pipe = None if args.serial else HopPipeline(dn, B)
+    if rehearsal:
+        pipe = dn.pipe(B)
+    else:
+        from audio_denoising_amd.pipeline import HopPipeline
+        pipe = None if args.serial else HopPipeline(dn, B)
 
     def step(i):
         if pipe is None:
             dn.process_frame_(frames, hx, out, seed=1000 + i, stream_id0=lo)
         else:
-            pipe.submit(frames, hx, out, seed=1000 + i, stream_id0=lo)
+            pipe.submit(frames, hx, out, seed=1000, stream_id0=lo, check_weights=False)
+
+    def sync():
+        if on_gpu:
+            torch.cuda.synchronize()
 
     def fence():
         if pipe is not None:
             pipe.flush()
-        torch.cuda.synchronize()
+        sync()
         if dist is not None:
             dist.barrier(device_ids=[dev.index]) if backend == "nccl" else dist.barrier()
-        torch.cuda.synchronize()
+        sync()
 
     # untimed: bring the GPU out of its idle power state first (a cold start ran the first few hundred hops at roughly
     # half clock: 124 us/step instead of 68), then the W warm-up steps of the contract
     t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < 0.5:
+    while on_gpu and time.perf_counter() - t_pre < 0.5:
         for i in range(50):
             step(i)
-        torch.cuda.synchronize()
+        sync()
     for i in range(args.warmup):
         step(i)
     fence()
@@ -273,11 +452,31 @@ def main():
     if rank == 0:
         print(f"[bench] {args.steps} steps x {B * world} frames in {elapsed:.4f} s", file=sys.stderr, flush=True)
 
+    ingress = None
+    if world > 1 and pipe is not None:
+        ingress = ingress_variant(dn, pipe, B, world, rank, dev, lo, args.steps, args.warmup, dist, backend, fence, on_gpu)
+
     line = None
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
         value = B * world * args.steps / elapsed
-        # the same K steps strictly one after another on one stream (dn_process_frame), for reference
+        line = {
+            "metric": METRIC,
+            "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic" if on_gpu else "rehearsal (rank plumbing only: no kernels ran)",
+            "ranks_seen": ranks_seen, "ingress": "local",
+            "config": {"workload": "configs[1]: batch 256 synthetic 32 ms frames per GPU, n_fft=1024 hop=512 n_mels=80, GRUUNet2 fp32 "
+                                   "(dari_tult weights, num_compressed_bins=5), 32-iter Griffin-Lim, device-RNG initial phases, hx carried; "
+                                   "every step re-processes the same 256 resident frames per GPU (the path is compute-bound: no data-dependent work)",
+                       "streams_per_gpu": B, "frames_per_step": B * world, "sample_rate": SR, "n_fft": N_FFT, "hop": HOP,
+                       "n_mels": N_MELS, "griffinlim_iters": GL_ITERS, "conv_precision": args.conv,
+                       "parallelism": f"stream-sharded x{world} (no data-path collective)"},
+        }
+        if ingress is not None:
+            line["ingress_variant"] = ingress
+    if rank == 0 and on_gpu:
+        # the same K steps strictly one after another, nothing overlapped (dn_process_frame: one launch, no added hop of latency)
         torch.cuda.synchronize()
         ts = time.perf_counter()
         for i in range(args.steps):
@@ -286,7 +485,7 @@ def main():
         serial_ms = 1e3 * (time.perf_counter() - ts) / args.steps
         kt = staged_kernel_times(dn, frames, hx, min(args.steps, 100))
         # dominant kernel of the timed region: hop_kernel.  Mean launch duration from HIP events recorded on the launch
-        # stream around each of 100 further pipelined hops (each launch = one whole hop of work for the batch).
+        # stream around a run of back-to-back launches (each launch = one whole hop of work for the batch).
         if pipe is not None:
             # (one event pair around a run of back-to-back launches: an event between every two launches adds ~4 us each)
             n_ev = min(args.steps, 100)
@@ -294,49 +493,53 @@ def main():
             pipe.submit(frames, hx, out, seed=1, stream_id0=lo)
             e0.record()
             for i in range(n_ev):
-                pipe.submit(frames, hx, out, seed=2 + i, stream_id0=lo)
+                pipe.submit(frames, hx, out, seed=1, stream_id0=lo, check_weights=False)
             e1.record()
             pipe.flush()
             torch.cuda.synchronize()
             dom_ms = e0.elapsed_time(e1) / n_ev
             dom_name, dom_flop = "hop_kernel (hop n Griffin-Lim blocks + hop n+1 analysis/model/inverse-mel blocks)", TOTAL_FLOP_PER_FRAME
-            dom_note = ("fp32 compute roof (FFT butterflies on the fp32 VALU, convs on fp32 MFMA; vector and matrix fp32 peaks are both 157.3 TF); "
+            dom_note = ("fp32-VALU bound (78 % of the flops are FFT butterflies on the fp32 vector ALU, the convs run on fp32 MFMA; vector and matrix "
+                        "fp32 peaks are both 157.3 TF, so one roof serves both); "
                         "algorithmic = 6.50 MFLOP per frame (198 rFFT-1024 x 25,600 + mel + convs + inverse mel) x 256 frames per launch")
-            dom_bytes = HBM_BYTES_PER_FRAME
         else:
-            dom_ms, dom_name, dom_flop = kt["synthesis"], "griffinlim_kernel<from mel> (P8-P12)", GL_FLOP_PER_FRAME
-            dom_note = "fp32 compute roof; algorithmic = (195 rFFT-1024 x 25,600 + 246,240 inverse-mel) flop per frame x 256 frames per launch"
-            dom_bytes = GL_HBM_BYTES_PER_FRAME
+            n_ev = min(args.steps, 100)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(n_ev):
+                dn.process_frame_(frames, hx, out, seed=1 + i, stream_id0=lo)
+            e1.record()
+            torch.cuda.synchronize()
+            dom_ms = e0.elapsed_time(e1) / n_ev
+            dom_name, dom_flop = "frame_kernel (P1-P12 of one stream per workgroup, nothing overlapped)", TOTAL_FLOP_PER_FRAME
+            dom_note = "fp32-VALU bound; algorithmic = 6.50 MFLOP per frame x 256 frames per launch"
         gl_s = dom_ms * 1e-3
         ach = dom_flop * B / gl_s / 1e12
         traffic = None
         pmc = os.path.join(REPO, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
-            traffic = json.load(open(pmc)).get("hop_kernel_hbm_bytes_per_launch" if pipe is not None else "griffinlim_kernel_hbm_bytes_per_launch")
-        line = {
-            "metric": "denoised audio frames/sec (32 ms, 16 kHz, hop 512) at batch 256; 1/2/4/8 GPU",
-            "value": round(value, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: batch 256 synthetic 32 ms frames per GPU, n_fft=1024 hop=512 n_mels=80, GRUUNet2 fp32 "
-                                   "(dari_tult weights, num_compressed_bins=5), 32-iter Griffin-Lim, device-RNG initial phases, hx carried",
-                       "streams_per_gpu": B, "frames_per_step": B * world, "sample_rate": SR, "n_fft": N_FFT, "hop": HOP,
-                       "n_mels": N_MELS, "griffinlim_iters": GL_ITERS, "parallelism": f"stream-sharded x{world} (no data-path collective)"},
-            "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": round(ach, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+            traffic = json.load(open(pmc)).get("hop_kernel_hbm_bytes_per_launch" if pipe is not None else "frame_kernel_hbm_bytes_per_launch")
+        bf16 = args.conv == "bf16"
+        conv_peak = PEAK_BF16_TFLOPS if bf16 else PEAK_FP32_TFLOPS
+        conv_ach = CONV_FLOP_PER_FRAME * B / (kt["cell"] * 1e-3) / 1e12
+        line.update({
+            "roofline": {"bound": "mfma", "bound_detail": "fp32-valu (FFT butterflies) + fp32 MFMA (convs): the fp32 compute roof, 157.3 TFLOP/s either way",
+                         "kernel": dom_name, "achieved": round(ach, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach / PEAK_FP32_TFLOPS, 4), "traffic": traffic, "note": dom_note,
                          "launch_ms": round(dom_ms, 4),
-                         "hbm_frac": round(dom_bytes * B / gl_s / 1e9 / PEAK_HBM_GBS, 6)},
+                         "hbm_frac": round(HBM_BYTES_PER_FRAME * B / gl_s / 1e9 / PEAK_HBM_GBS, 6)},
             "kernel_ms": {k: round(v, 4) for k, v in kt.items()},
-            # MFMA utilisation of the UNet convs: conv FLOPs / (serial cell_kernel time x fp32 MFMA peak)
-            "conv_mfma": {"kernel": "cell_kernel (fp32 v_mfma_f32_16x16x4_f32)", "achieved": round(939150 * B / (kt["cell"] * 1e-3) / 1e12, 3),
-                          "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(939150 * B / (kt["cell"] * 1e-3) / 1e12 / PEAK_FP32_TFLOPS, 4),
-                          "note": "0.24 GFLOP per batch-256 launch is 1.5 us at peak: structurally latency-bound (SURVEY section 7)"},
-            "schedule": "serial, 3 launches per hop (dn_process_frame)" if pipe is None else "software-pipelined, 1 launch per hop (dn_pipe_submit)",
+            # MFMA utilisation of the UNet convs: conv FLOPs / (stand-alone cell kernel time x MFMA peak of the conv dtype)
+            "conv_mfma": {"kernel": "cell_kernel_bf16 (v_mfma_f32_16x16x32_bf16)" if bf16 else "cell_kernel (fp32 v_mfma_f32_16x16x4_f32)",
+                          "achieved": round(conv_ach, 3), "peak": conv_peak, "unit": "TFLOP/s", "frac": round(conv_ach / conv_peak, 5),
+                          "note": "0.24 GFLOP per batch-256 launch is 1.5 us at the fp32 peak: structurally latency-bound (SURVEY section 7)"},
+            "schedule": "unpipelined, 1 launch per hop (dn_process_frame), no added latency" if pipe is None
+                        else "software-pipelined, 1 launch per hop (dn_pipe_submit): output delayed by one hop",
             "serial_ms_per_step": round(serial_ms, 4),
             "whole_path": {"tflops": round(TOTAL_FLOP_PER_FRAME * value / 1e12, 3),
                            "fp32_frac": round(TOTAL_FLOP_PER_FRAME * value / 1e12 / (PEAK_FP32_TFLOPS * world), 4),
                            "hbm_frac": round(HBM_BYTES_PER_FRAME * value / 1e9 / (PEAK_HBM_GBS * world), 6)},
-        }
+        })
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
     if dist is not None:

@@ -49,7 +49,7 @@ int main(int argc, char** argv) {
                 h[b * N + n] = (float)(0.3 * sin(2 * M_PI * (220.0 + 110.0 * b) * t) + 0.05 * sin(2 * M_PI * 3300.0 * t + b));
             }
         CHECK_HIP(hipMemcpyAsync(frames, h.data(), sizeof(float) * B * N, hipMemcpyHostToDevice, st));
-        CHECK_DN(dn_process_frame(model, plan, frames, hx, out, nullptr, nullptr, /*seed*/ 2024 + hop, /*stream_id0*/ 0, 32, 0.99f, ws, B, st));
+        CHECK_DN(dn_process_frame(model, plan, frames, hx, out, nullptr, nullptr, /*seed*/ 2024 + hop, /*stream_id0*/ 0, 32, 0.99f, ws, B, /*flags*/ 0, st));
     }
     CHECK_HIP(hipMemcpyAsync(h.data(), out, sizeof(float) * B * N, hipMemcpyDeviceToHost, st));
     CHECK_HIP(hipStreamSynchronize(st));

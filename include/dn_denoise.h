@@ -25,7 +25,8 @@
  *   dn_stft_general / dn_server_rows / dn_istft_general / dn_cell_forward_ex   server.py:199-217  the socket server's variant
  *   dn_process_frame                    app3.py:178-217  the whole per-hop loop body for B streams
  *   dn_stream_step                      app3.py:178-226  the same plus ring buffer / overlap-add state (P12)
- *   dn_pipe_*                           app3.py:178-217  the same hop, consecutive hops software-pipelined in one launch per hop
+ *   dn_pipe_*                           app3.py:167-250  the same hop, consecutive hops software-pipelined in one launch per hop
+ *                                       (dn_pipe_stream_*: the steady-state recv loop with its per-stream buffers)
  *
  * Memory layouts (row-major, fp32; "complex" = interleaved re,im float pairs):
  *   frames      [B][n_fft]
@@ -49,7 +50,7 @@
 extern "C" {
 #endif
 
-#define DN_ABI_VERSION 1
+#define DN_ABI_VERSION 2
 
 typedef enum dn_status {
     DN_OK = 0,
@@ -170,23 +171,28 @@ int dn_server_rows(const dn_dsp* d, const float* logmel, const float* model_out,
                    int32_t rows, void* stream);
 int dn_istft_general(const dn_dsp* d, const float* spec, float* wave, int32_t B, int32_t T, void* stream);
 
+/* flags of the fused entry points */
+#define DN_CONV_BF16 1u /* BASELINE config 3: encoder/decoder convs on bf16 MFMA tiles (as dn_cell_forward_bf16); 0 = exact fp32 */
+
 /* Scratch the fused entry points need, in bytes, for a batch of B streams. */
 size_t dn_workspace_bytes(const dn_dsp* d, int32_t B);
 
 /* The whole per-hop body for B streams (app3.py:178-217): frames [dev][B][n_fft] raw samples,
  * hx [dev][B][17][C] in/out, out [dev][B][n_fft] = GriffinLim(...) * peak.
  * mel_residual_out [dev][B][3][M] or NULL receives the model output (predicted_diff_mel).
- * workspace [dev] of dn_workspace_bytes(d, B) bytes.  Three launches: dn_stft_mel_log1p, dn_cell_forward, dn_synthesis. */
+ * workspace [dev] of dn_workspace_bytes(d, B) bytes.  ONE launch (one workgroup per stream runs P1-P12 back to back);
+ * no hop of added latency.  flags: DN_CONV_BF16 or 0. */
 int dn_process_frame(const dn_model* m, const dn_dsp* d, const float* frames, float* hx, float* out,
                      float* mel_residual_out, const float* init_angles, uint64_t seed, uint64_t stream_id0,
-                     int32_t n_iter, float momentum, void* workspace, int32_t B, void* stream);
+                     int32_t n_iter, float momentum, void* workspace, int32_t B, uint32_t flags, void* stream);
 
 /* Streaming step (app3.py:178-226): ring [dev][B][n_fft] holds the last n_fft input samples per stream;
  * hop_in [dev][B][hop] new samples are shifted in first.  ola [dev][B][n_fft] is the output
- * overlap-add buffer; hop_out [dev][B][hop] receives ola[:hop] before the shift (app3.py:219-224). */
+ * overlap-add buffer; hop_out [dev][B][hop] receives ola[:hop] before the shift (app3.py:219-224).
+ * ONE launch; every argument is validated before it, so a failed call leaves ring, ola and hx untouched. */
 int dn_stream_step(const dn_model* m, const dn_dsp* d, const float* hop_in, float* ring, float* ola, float* hx,
                    float* hop_out, const float* init_angles, uint64_t seed, uint64_t stream_id0, int32_t n_iter,
-                   float momentum, void* workspace, int32_t B, void* stream);
+                   float momentum, void* workspace, int32_t B, uint32_t flags, void* stream);
 
 /* ---- Software-pipelined hops ------------------------------------------------------------------------
  * Consecutive hops depend on each other only through hx (the model); hop n's Griffin-Lim (~3/4 of a hop) is
@@ -194,14 +200,33 @@ int dn_stream_step(const dn_model* m, const dn_dsp* d, const float* hop_in, floa
  * dn_pipe_submit(hop n+1) launches a grid whose first B workgroups run hop n's Griffin-Lim and whose next B run
  * hop n+1's P1-P10 (double-buffered scratch); dn_pipe_flush launches the last pending Griffin-Lim.  Everything is
  * enqueued on `stream`; the output of a submitted hop is complete (in stream order) after the NEXT submit or the
- * flush.  `frames`, `hx`, `out` and `init_angles` of a submit must stay valid and untouched until then (hx is
- * advanced in place, hop by hop). */
+ * flush.  `frames`, `hx` and `out` of a submit must stay valid and untouched until then (hx is advanced in place, hop by
+ * hop); `init_angles` is copied during the submit and is free again once that launch ran.
+ *
+ * Replayable launches: everything that changes from hop to hop (scratch-slot parity, whether a hop is pending, the ring
+ * priming of new streams, the frame index that keys the Griffin-Lim seed) lives in a device-resident control block that the
+ * last workgroup of every launch advances.  A dn_pipe_submit / dn_pipe_stream_push captured into a hipGraph can therefore be
+ * replayed indefinitely (BASELINE config 5: the captured streaming step); the caller rewrites the contents of the buffers
+ * whose pointers were captured.  The Griffin-Lim of frame f draws its phases from (seed + f, stream_id0 + stream), f counted
+ * per pipe from 0 (dn_pipe_stream_set_state can restore it), so a replayed launch does not repeat phases and a resumed
+ * stream continues the sequence of the uninterrupted one.
+ *
+ * A pipe holds a reference on its model and plan: dn_model_destroy / dn_dsp_destroy while a pipe still uses them only drop
+ * the creator's reference.  dn_pipe_set_model rebinds a pipe to other weights between two launches (launches already
+ * enqueued keep reading the old model: keep it alive until they have run).  flags: DN_CONV_BF16 or 0. */
 typedef struct dn_pipe dn_pipe;
-int dn_pipe_create(const dn_model* m, const dn_dsp* d, int32_t B, dn_pipe** out);
+int dn_pipe_create(const dn_model* m, const dn_dsp* d, int32_t B, uint32_t flags, dn_pipe** out);
 void dn_pipe_destroy(dn_pipe* p);
+int dn_pipe_set_model(dn_pipe* p, const dn_model* m);
+/* Allocates the per-slot buffers for injected initial phases now (otherwise the first submit/push with init_angles does it):
+ * call before capturing a parity-mode launch into a hipGraph, where allocation is not allowed. */
+int dn_pipe_reserve_parity(dn_pipe* p);
 int dn_pipe_submit(dn_pipe* p, const float* frames, float* hx, float* out, const float* init_angles, uint64_t seed,
                    uint64_t stream_id0, int32_t n_iter, float momentum, void* stream);
-int dn_pipe_flush(dn_pipe* p, void* stream);
+/* Runs the pending hop's Griffin-Lim (n_iter / momentum as for the submits); a no-op launch when nothing is pending. */
+int dn_pipe_flush(dn_pipe* p, int32_t n_iter, float momentum, void* stream);
+/* Host copy of the control block (pushes, frames, pending; any may be NULL).  Synchronises `stream`. */
+int dn_pipe_get_counters(dn_pipe* p, uint64_t* pushes, uint64_t* frames, int32_t* pending, void* stream);
 
 /* Streaming form (BASELINE config 5; app3.py:168-250 without the av container): the pipe owns the per-stream state
  * (input ring, output overlap-add line, hx -- app3.py:130-133) in HBM and every push is ONE launch.
@@ -210,18 +235,19 @@ int dn_pipe_flush(dn_pipe* p, void* stream);
  * The first n_fft/hop - 1 pushes only fill the ring.  Because hops are software-pipelined, the samples the reference
  * would emit while processing frame f (ola[:hop] before frame f is added, app3.py:219-220) come out of the push
  * that follows the one that delivered frame f's last hop -- one hop of extra latency; zeros until then.
- * dn_pipe_stream_flush emits the last pending hop.  init_angles (NULL = device RNG) must stay valid until the next
- * push/flush. */
-int dn_pipe_stream_create(const dn_model* m, const dn_dsp* d, int32_t B, dn_pipe** out);
+ * dn_pipe_stream_flush emits the last pending hop (zeros when none is pending). */
+int dn_pipe_stream_create(const dn_model* m, const dn_dsp* d, int32_t B, uint32_t flags, dn_pipe** out);
 int dn_pipe_stream_push(dn_pipe* p, const void* hop_in, int32_t in_is_s16, void* hop_out, int32_t out_is_s16,
                         const float* init_angles, uint64_t seed, uint64_t stream_id0, int32_t n_iter, float momentum,
                         void* stream);
-int dn_pipe_stream_flush(dn_pipe* p, void* hop_out, int32_t out_is_s16, void* stream);
+int dn_pipe_stream_flush(dn_pipe* p, void* hop_out, int32_t out_is_s16, int32_t n_iter, float momentum, void* stream);
 /* Checkpoint / resume of live streams: copy the pipe-owned state out to / in from caller buffers [dev]
- * (ring [B][n_fft], ola [B][n_fft], hx [B][17][C]; any may be NULL), ordered on `stream`.  set_state requires that no
- * hop is pending (call dn_pipe_stream_flush first); a restored ring counts as primed. */
+ * (ring [B][n_fft], ola [B][n_fft], hx [B][17][C]; any may be NULL), ordered on `stream`.  Take snapshots after
+ * dn_pipe_stream_flush: set_state drops a pending hop.  A restored ring counts as primed; frames_done (the `frames`
+ * counter of dn_pipe_get_counters at snapshot time) makes the resumed stream continue the seed sequence. */
 int dn_pipe_stream_get_state(dn_pipe* p, float* ring, float* ola, float* hx, void* stream);
-int dn_pipe_stream_set_state(dn_pipe* p, const float* ring, const float* ola, const float* hx, void* stream);
+int dn_pipe_stream_set_state(dn_pipe* p, const float* ring, const float* ola, const float* hx, uint64_t frames_done,
+                             void* stream);
 
 const char* dn_last_error(void);
 int dn_abi_version(void);

@@ -124,6 +124,8 @@ inline float shfl(float v, int src) {
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) dn_emu::launch(kernel, grid, block, __VA_ARGS__)
 
 inline void __syncthreads() { dn_emu::ctx.block->wait(); }
+// workgroups run one after another and one thread per workgroup takes the ticket: a plain read-modify-write is enough
+inline unsigned int atomicAdd(unsigned int* p, unsigned int v) { unsigned int o = *p; *p = o + v; return o; }
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 #define __builtin_amdgcn_wave_barrier() dn_emu::ctx.wave->wait()
 #define __builtin_amdgcn_readfirstlane(x) (x)

@@ -164,7 +164,7 @@ def test_process_frame_and_stream_step_match_oracle(lib, dsp):
         ia = emu.f32(np.stack([ia.real, ia.imag], axis=-1))
         hop_out = np.zeros((B, P.hop), np.float32)
         lib.check(lib.dn_stream_step(m, dsp, emu.ptr(hop_in), emu.ptr(ring), emu.ptr(ola), emu.ptr(hx), emu.ptr(hop_out),
-                                     emu.ptr(ia), 0, 0, 32, 0.99, emu.ptr(ws), B, None))
+                                     emu.ptr(ia), 0, 0, 32, 0.99, emu.ptr(ws), B, 0, None))
         outs.append(hop_out)
     lib.dn_model_destroy(m)
     got = np.concatenate(outs, axis=1)
@@ -184,14 +184,14 @@ def test_pipelined_hops_equal_serial_hops(lib, dsp):
     outs_a = [np.zeros((B, P.n_fft), np.float32) for _ in range(n_hops)]
     for h in range(n_hops):
         lib.check(lib.dn_process_frame(m, dsp, emu.ptr(frames[h]), emu.ptr(hx_a), emu.ptr(outs_a[h]), None, None, 11 + h, 3, 32, 0.99,
-                                       emu.ptr(ws), B, None))
+                                       emu.ptr(ws), B, 0, None))
     pipe = C.c_void_p()
-    lib.check(lib.dn_pipe_create(m, dsp, B, C.byref(pipe)))
+    lib.check(lib.dn_pipe_create(m, dsp, B, 0, C.byref(pipe)))
     hx_b = np.zeros((B, 17, 5), np.float32)
     outs_b = [np.zeros((B, P.n_fft), np.float32) for _ in range(n_hops)]
     for h in range(n_hops):
-        lib.check(lib.dn_pipe_submit(pipe, emu.ptr(frames[h]), emu.ptr(hx_b), emu.ptr(outs_b[h]), None, 11 + h, 3, 32, 0.99, None))
-    lib.check(lib.dn_pipe_flush(pipe, None))
+        lib.check(lib.dn_pipe_submit(pipe, emu.ptr(frames[h]), emu.ptr(hx_b), emu.ptr(outs_b[h]), None, 11, 3, 32, 0.99, None))     # frame h draws from seed + h
+    lib.check(lib.dn_pipe_flush(pipe, 32, 0.99, None))
     lib.dn_pipe_destroy(pipe)
     lib.dn_model_destroy(m)
     assert np.array_equal(hx_a, hx_b)
@@ -206,7 +206,7 @@ def test_streaming_pipe_matches_oracle_with_one_hop_delay(lib, dsp):
     sig, inits = g["signal"][:B], g["init_angles"][:, :B]
     m = make_model(lib, 5)
     pipe = C.c_void_p()
-    lib.check(lib.dn_pipe_stream_create(m, dsp, B, C.byref(pipe)))
+    lib.check(lib.dn_pipe_stream_create(m, dsp, B, 0, C.byref(pipe)))
     outs, keep = [], []
     for p_i in range(n_frames + 1):                      # push 0 primes the ring; push f+1 delivers frame f
         hop_in = emu.f32(sig[:, p_i * P.hop:(p_i + 1) * P.hop])
@@ -219,7 +219,7 @@ def test_streaming_pipe_matches_oracle_with_one_hop_delay(lib, dsp):
         lib.check(lib.dn_pipe_stream_push(pipe, emu.ptr(hop_in), 0, emu.ptr(out), 0, emu.ptr(ia), 0, 0, 32, 0.99, None))
         outs.append(out)
     last = np.zeros((B, P.hop), np.float32)
-    lib.check(lib.dn_pipe_stream_flush(pipe, emu.ptr(last), 0, None))
+    lib.check(lib.dn_pipe_stream_flush(pipe, emu.ptr(last), 0, 32, 0.99, None))
     outs.append(last)
     assert np.all(outs[0] == 0) and np.all(outs[1] == 0)                      # nothing to emit yet
     got = np.concatenate(outs[2:], axis=1)                                    # segments of frames 0..n_frames-1
@@ -228,9 +228,9 @@ def test_streaming_pipe_matches_oracle_with_one_hop_delay(lib, dsp):
     lib.dn_pipe_destroy(pipe)
     # int16 in / int16 out: quantised input through the float path must give the same samples, quantised
     pipe = C.c_void_p()
-    lib.check(lib.dn_pipe_stream_create(m, dsp, B, C.byref(pipe)))
+    lib.check(lib.dn_pipe_stream_create(m, dsp, B, 0, C.byref(pipe)))
     pipe_f = C.c_void_p()
-    lib.check(lib.dn_pipe_stream_create(m, dsp, B, C.byref(pipe_f)))
+    lib.check(lib.dn_pipe_stream_create(m, dsp, B, 0, C.byref(pipe_f)))
     for p_i in range(3):
         q = np.clip(np.round(sig[:, p_i * P.hop:(p_i + 1) * P.hop] * 3.0 * 32767), -32768, 32767).astype(np.int16)
         qf = emu.f32(q.astype(np.float32) / np.float32(32767))
@@ -283,7 +283,7 @@ def test_r1_process_frame_matches_oracle(lib, dsp_r1):
     ia = g["init_angles"][:B].transpose(0, 2, 1)
     ia = emu.f32(np.stack([ia.real, ia.imag], axis=-1))
     lib.check(lib.dn_process_frame(m, dsp_r1, emu.ptr(frames), emu.ptr(hx), emu.ptr(out), emu.ptr(resid), emu.ptr(ia), 0, 0, 32, 0.99,
-                                   emu.ptr(ws), B, None))
+                                   emu.ptr(ws), B, 0, None))
     lib.dn_model_destroy(m)
     assert np.abs(resid - g["predicted_diff"][:B]).max() <= 1e-4
     assert np.abs(hx - g["hx"][:B]).max() <= 1e-4

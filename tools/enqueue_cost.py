@@ -7,11 +7,11 @@ dn = bench.build_denoiser(dev)
 B = 256
 frames = (0.1 * torch.randn(B, 1024)).to(dev); hx = dn.init_hx(B); out = torch.empty_like(frames)
 pipe = HopPipeline(dn, B)
-for i in range(20): pipe.submit(frames, hx, out, seed=i)
+for i in range(20): pipe.submit(frames, hx, out, seed=0)
 pipe.flush(); torch.cuda.synchronize()
 for K in (200,):
     t0 = time.perf_counter()
-    for i in range(K): pipe.submit(frames, hx, out, seed=i)
+    for i in range(K): pipe.submit(frames, hx, out, seed=0)
     t1 = time.perf_counter()
     pipe.flush(); torch.cuda.synchronize()
     t2 = time.perf_counter()

@@ -27,7 +27,7 @@ def main():
         from audio_denoising_amd.pipeline import HopPipeline
         pipe = HopPipeline(dn, batch)
         for i in range(steps):
-            pipe.submit(frames, hx, out, seed=1000 + i, stream_id0=0)
+            pipe.submit(frames, hx, out, seed=1000, stream_id0=0)
         pipe.flush()
     torch.cuda.synchronize()
     print("ok", float(out.abs().mean()))
