@@ -136,6 +136,7 @@ using std::max;
 using std::min;
 inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 inline float __builtin_amdgcn_sqrtf(float x) { return std::sqrt(x); }
+inline float __builtin_amdgcn_rsqf(float x) { return 1.0f / std::sqrt(x); }
 
 // v_mfma_f32_16x16x4_f32 emulated as a wave-collective op: D = A(16x4) B(4x16) + C with
 // lane l supplying A[l & 15][l >> 4], B[l >> 4][l & 15] and holding D[(l >> 4) * 4 + r][l & 15].

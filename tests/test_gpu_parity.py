@@ -18,6 +18,21 @@ pytestmark = pytest.mark.gpu
 
 TOL_RESIDUAL = 1e-4
 TOL_WAVE_RMS = 1e-3
+# Next to every RMS check there is a max-abs bound, so that a single bad sample per frame cannot hide in the mean: 32 Griffin-Lim
+# iterations amplify fp32 rounding differences ~100x (1e-6 relative on the magnitudes -> 1e-4 on the waveform),
+# measured max-abs on the MI355X is 1e-5 .. 3e-4 on signals of RMS 0.05 .. 0.1; the bound is 20x the RMS bar.
+TOL_WAVE_MAX = 2e-2
+# hx after a chain of hops fed by the fp32 DSP front end (the model input itself differs from the oracle's by ~2e-5, P5): measured
+# <= 6e-5 after 30 chained steps (stream_S), bound 2e-4.  (The model stage alone holds 1e-4: test_gruunet2_chain_of_20_hops.)
+TOL_HX_STREAM = 2e-4
+
+
+def _wave_close(got, ref, scale=1.0):
+    """RMS and max-abs waveform bounds together (numpy arrays)."""
+    err = np.asarray(got, dtype=np.float64) - np.asarray(ref, dtype=np.float64)
+    rms, mx = float(np.sqrt(np.mean(err ** 2))), float(np.abs(err).max())
+    assert rms <= TOL_WAVE_RMS * scale and mx <= TOL_WAVE_MAX * scale, (rms, mx)
+    return rms, mx
 CFG = dict(in_size=1, hidden_sizes=(17, 17, 17, 17), kernel_sizes=(3, 3, 3, 3), strides=(2, 2, 2, 2), paddings=(1, 1, 1, 1), num_gaussians=6)
 
 
@@ -142,7 +157,7 @@ def test_transform_chain_as_the_app_calls_it(dev, tag):
     assert np.abs(lin.cpu().numpy() - g["lin_mag"]).max() <= 2e-4 * max(1.0, float(np.abs(g["lin_mag"]).max()))
     y = GL(torch.from_numpy(g["lin_mag"]).to(dev), init_angles=torch.from_numpy(g["init_angles"]).to(dev))   # P11
     ref_y = g["out"] / g["peak"][:, None]
-    assert np.sqrt(np.mean((y.cpu().numpy() - ref_y) ** 2)) <= TOL_WAVE_RMS
+    _wave_close(y.cpu().numpy(), ref_y)
 
 
 def test_inverse_spectrogram_round_trip_and_linearity_at_full_batch(dev):
@@ -197,7 +212,7 @@ def test_process_frame_matches_oracle_golden(dev, tag):
     out, hx, resid = dn.process_frame(frames, None, init_angles=torch.from_numpy(g["init_angles"]).to(dev), return_residual=True)
     assert np.abs(resid.cpu().numpy() - g["predicted_diff"]).max() <= TOL_RESIDUAL
     assert np.abs(hx.cpu().numpy() - g["hx"]).max() <= TOL_RESIDUAL
-    assert np.sqrt(np.mean((out.cpu().numpy() - g["out"]) ** 2)) <= TOL_WAVE_RMS
+    _wave_close(out.cpu().numpy(), g["out"])
     # silent / sub-threshold streams (peak <= 1e-6 -> no normalisation, app3.py:182-186) stay finite and match the oracle
     assert torch.isfinite(out).all()
     assert np.abs(out.cpu().numpy()[4:6] - g["out"][4:6]).max() <= 1e-3
@@ -219,7 +234,7 @@ def test_process_frame_full_batch_vs_oracle_sample_and_shard_invariance(dev):
     with torch.no_grad():
         ref = pipeline_ref.process_frame(_state_dict("dari_tult"), frames[idx], torch.zeros(len(idx), 17, 5), p, fb, init_angles=init[idx])
     assert (resid.cpu()[idx] - ref["predicted_diff"]).abs().max().item() <= TOL_RESIDUAL
-    assert (out.cpu()[idx] - ref["out"]).pow(2).mean().sqrt().item() <= TOL_WAVE_RMS
+    _wave_close(out.cpu()[idx].numpy(), ref["out"].numpy())
     # device-RNG path: sharding must not change a single bit
     fd = frames.to(dev)
     whole, hw = dn.process_frame(fd, None, seed=99, stream_id0=0)
@@ -271,9 +286,9 @@ def test_streaming_matches_oracle_golden(dev):
         outs.append(st.push(sig[:, a:b].contiguous(), init_angles_per_hop=inits[st.hops:]))
     y = torch.cat(outs, 1).cpu().numpy()
     assert y.shape == g["out"].shape
-    assert np.sqrt(np.mean((y - g["out"]) ** 2)) <= TOL_WAVE_RMS
-    assert np.sqrt(np.mean((st.ola.cpu().numpy() - g["ola"]) ** 2)) <= TOL_WAVE_RMS
-    assert np.abs(st.hx.cpu().numpy() - g["hx"]).max() <= 5e-4    # hx after 30 chained steps fed by the fp32 DSP front end
+    _wave_close(y, g["out"])
+    _wave_close(st.ola.cpu().numpy(), g["ola"])
+    assert np.abs(st.hx.cpu().numpy() - g["hx"]).max() <= TOL_HX_STREAM    # hx after 30 chained steps fed by the fp32 DSP front end
     assert st.push(torch.zeros(4, 0, device=dev)).shape == (4, 0)  # empty push: nothing emitted
 
 
@@ -296,11 +311,11 @@ def test_pipelined_stream_matches_oracle_golden_with_one_hop_delay(dev):
     assert float(outs[0].abs().max()) == 0.0 and float(outs[1].abs().max()) == 0.0
     y = torch.cat(outs[2:], 1).cpu().numpy()
     assert y.shape == g["out"].shape
-    assert np.sqrt(np.mean((y - g["out"]) ** 2)) <= TOL_WAVE_RMS
+    _wave_close(y, g["out"])
     ring, ola, hx, frames_done = ps.state()
     assert frames_done == n_frames and ps.counters() == (n_frames + 1, n_frames, False)
-    assert np.sqrt(np.mean((ola.cpu().numpy() - g["ola"]) ** 2)) <= TOL_WAVE_RMS
-    assert np.abs(hx.cpu().numpy() - g["hx"]).max() <= 5e-4
+    _wave_close(ola.cpu().numpy(), g["ola"])
+    assert np.abs(hx.cpu().numpy() - g["hx"]).max() <= TOL_HX_STREAM
     assert torch.equal(ring.cpu(), torch.from_numpy(g["signal"])[:, -p.n_fft:])
     # checkpoint / resume of live streams: a second pipe restored from the snapshot continues identically
     ps2 = PipelinedStream(dn, 4)
@@ -333,13 +348,14 @@ def test_app_parameters_streaming_serial_and_pipelined(dev):
     inits = [torch.from_numpy(a).to(dev) for a in g["init_angles"]]
     st = DenoiserStream(dn, 3)
     y = st.push(sig, init_angles_per_hop=inits).cpu().numpy()
-    assert y.shape == g["out"].shape and np.sqrt(np.mean((y - g["out"]) ** 2)) <= TOL_WAVE_RMS
-    assert np.abs(st.hx.cpu().numpy() - g["hx"]).max() <= 5e-4
+    assert y.shape == g["out"].shape
+    _wave_close(y, g["out"])
+    assert np.abs(st.hx.cpu().numpy() - g["hx"]).max() <= TOL_HX_STREAM
     ps = PipelinedStream(dn, 3)
     outs = [ps.push(sig[:, i * p.hop:(i + 1) * p.hop].contiguous(), init_angles=inits[i - 1] if i >= 1 else None) for i in range(len(inits) + 1)]
     outs.append(ps.flush())
     y2 = torch.cat(outs[2:], 1).cpu().numpy()
-    assert np.sqrt(np.mean((y2 - g["out"]) ** 2)) <= TOL_WAVE_RMS
+    _wave_close(y2, g["out"])
     # size-independent property at the app's parameters: istft(stft(x)) == x for a full batch
     from audio_denoising_amd import transforms as T
     T0 = T.Spectrogram(power=None, n_fft=p.n_fft, win_length=p.n_fft, hop_length=p.hop).to(dev)
@@ -470,7 +486,7 @@ def test_captured_streaming_step_replays_at_1024_streams(dev):
         assert torch.equal(x, y)
     y = torch.cat(replayed[2:], 1).cpu().numpy().reshape(rep, 4, -1)
     err = y - g["out"][None]
-    assert np.sqrt(np.mean(err ** 2)) <= TOL_WAVE_RMS and np.abs(err).max() <= 2e-2
+    assert np.sqrt(np.mean(err ** 2)) <= TOL_WAVE_RMS and np.abs(err).max() <= TOL_WAVE_MAX
     assert np.array_equal(y[0], y[rep - 1])                                                # copies of a stream agree exactly
     # device-RNG phases under replay: 12 more replays continue the seed sequence exactly as eager pushes do
     nxt = (0.05 * torch.randn(B, p.hop, generator=torch.Generator().manual_seed(8))).to(dev)
@@ -554,15 +570,15 @@ def test_server_variant_matches_oracle_golden(dev):
     for c in range(3):
         wave, hx = sd.process(torch.from_numpy(g["chunks"][c]).to(dev), hx)
         assert wave.shape == g["out"][c].shape
-        assert np.sqrt(np.mean((wave.cpu().numpy() - g["out"][c]) ** 2)) <= TOL_WAVE_RMS
-    assert np.abs(hx.cpu().numpy() - g["hx"]).max() <= 5e-4
+        _wave_close(wave.cpu().numpy(), g["out"][c])
+    assert np.abs(hx.cpu().numpy() - g["hx"]).max() <= TOL_HX_STREAM
     # ragged: a chunk that is not a multiple of the hop (the client of server.py sends e.g. 4800 samples)
     x = torch.randn(2, 4800, generator=torch.Generator().manual_seed(2)).to(dev) * 0.1
     w, _ = sd.process(x, None)
     assert w.shape == (2, p.hop * (4800 // p.hop)) and torch.isfinite(w).all()
     from oracle import model_ref, server_ref
     ref = server_ref.process_chunk(_state_dict("good"), x.cpu(), None, p)
-    assert (w.cpu() - ref["out"]).pow(2).mean().sqrt().item() <= TOL_WAVE_RMS
+    _wave_close(w.cpu().numpy(), ref["out"].numpy())
 
 
 def test_maximum_batch_streams_are_independent(dev):
@@ -628,8 +644,9 @@ def test_special_signals_match_oracle(dev, tag):
     assert (hx.cpu() - ref["hx"]).abs().max().item() <= TOL_RESIDUAL
     # waveform: per-frame RMS error relative to that frame's scale (outputs are multiplied back by the frame's peak)
     scale = torch.maximum(ref["peak"], torch.tensor(1.0))
-    err = ((out.cpu() - ref["out"]) / scale[:, None]).pow(2).mean(1).sqrt()
-    assert err.max().item() <= TOL_WAVE_RMS, err
+    rel = (out.cpu() - ref["out"]) / scale[:, None]
+    err = rel.pow(2).mean(1).sqrt()
+    assert err.max().item() <= TOL_WAVE_RMS and rel.abs().max().item() <= TOL_WAVE_MAX, (err, rel.abs().max())
 
 
 def test_c_abi_host_without_python_gives_the_same_samples(dev, tmp_path):
@@ -685,3 +702,89 @@ def test_bench_two_ranks_on_one_gpu(dev):
     assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["data"] == "synthetic" and d["config"]["frames_per_step"] == 512
     assert d["ingress_variant"]["ingress"] == "scatter_gather" and d["ingress_variant"]["root_output_finite"] is True
     assert d["roofline"]["frac"] > 0 and d["value"] > 0
+
+
+def test_real_clip_3s_batch1_streams_match_oracle_golden(dev):
+    """BASELINE configs[0] at its stated size: ONE 3 s / 16 kHz clip (93 hops, batch 1, dari_tult weights) of real audio from the
+    reference's data tree (tests/golden/clip_S.npz, made by oracle/make_clip_golden.py), streamed hop by hop as the app's recv()
+    does -- through DenoiserStream (no added latency), PipelinedStream (one hop later) and the int16 transport of app3.py:168-172."""
+    from audio_denoising_amd.pipeline import Denoiser, DenoiserStream, PipelinedStream
+    from oracle.make_clip_golden import N_HOPS, clip_init_angles
+    p = _params("S")
+    g = load_golden("clip_S.npz")
+    s16 = torch.from_numpy(g["signal_s16"])[None]
+    sig = torch.from_numpy(g["signal_s16"].astype(np.float32) / np.float32(32767))[None].to(dev)       # app3.py:172
+    inits = [clip_init_angles(f).to(dev) for f in range(N_HOPS)]
+    dn = Denoiser(_model(dev, 5), p.sample_rate, p.n_fft, p.hop, p.n_mels)
+    ref_rms = float(np.sqrt(np.mean(g["out"] ** 2)))
+    # (a) recv()-sized chunks of 480 samples (30 ms WebRTC frames) through the unpipelined stream
+    st = DenoiserStream(dn, 1)
+    outs = []
+    for a in range(0, sig.shape[1], 480):
+        outs.append(st.push(sig[:, a:a + 480].contiguous(), init_angles_per_hop=inits[st.hops:]))
+    y = torch.cat(outs, 1).cpu().numpy()
+    assert y.shape == g["out"].shape == (1, N_HOPS * p.hop)
+    rms, mx = _wave_close(y, g["out"])
+    assert rms <= 2e-2 * ref_rms                         # and relative to the (quiet) output itself
+    _wave_close(st.ola.cpu().numpy(), g["ola"])
+    assert np.abs(st.hx.cpu().numpy() - g["hx"]).max() <= TOL_HX_STREAM
+    # (b) one launch per hop, float samples
+    ps = PipelinedStream(dn, 1)
+    outs = [ps.push(sig[:, i * p.hop:(i + 1) * p.hop].contiguous(), init_angles=inits[i - 1] if i >= 1 else None) for i in range(N_HOPS + 1)]
+    outs.append(ps.flush())
+    y2 = torch.cat(outs[2:], 1).cpu().numpy()
+    _wave_close(y2, g["out"])
+    assert np.array_equal(y2, y)                         # the two schedules run the same arithmetic
+    # (c) int16 PCM in, int16 PCM out
+    ps16 = PipelinedStream(dn, 1)
+    q = s16.to(dev)
+    outs = [ps16.push(q[:, i * p.hop:(i + 1) * p.hop].contiguous(), init_angles=inits[i - 1] if i >= 1 else None) for i in range(N_HOPS + 1)]
+    outs.append(ps16.flush(s16=True))
+    y16 = torch.cat(outs[2:], 1).cpu().numpy()
+    want = (np.clip(g["out"], -1, 1) * 32767).astype(np.int16)
+    assert y16.dtype == np.int16 and np.abs(y16.astype(np.int32) - want.astype(np.int32)).max() <= int(TOL_WAVE_MAX * 32767) + 1
+
+
+def test_config3_bf16_conv_tiles_inside_the_whole_hop_batch256(dev):
+    """BASELINE config 3 as a whole hop: batch 256, S parameters, UNet convs on bf16 MFMA tiles (DN_CONV_BF16 /
+    GRUUNet2.conv_precision = "bf16") in the one-launch hop and in the software-pipelined hop.  Tolerance restated against the
+    ORACLE (fp32 reference arithmetic): mel residual rel-RMS <= 1e-2 and max-abs <= 5e-1 (as for dn_cell_forward_bf16); waveform
+    (shared initial phases; Griffin-Lim turns the ~3e-3 relative magnitude error into a different phase path, so the bound is set
+    from measurement on the MI355X -- RMS 1.2e-3, max-abs 0.012 on denoised frames of RMS 0.009, i.e. ~13 % of the signal where the
+    fp32 path holds 0.03 % -- with a 4x margin): RMS <= 5e-3, max-abs <= 5e-2."""
+    from audio_denoising_amd.pipeline import Denoiser, HopPipeline
+    from oracle import dsp_ref, pipeline_ref
+    p = pipeline_ref.PARAMS_S
+    m = _model(dev, 5)
+    m.conv_precision = "bf16"
+    dn = Denoiser(m, p.sample_rate, p.n_fft, p.hop, p.n_mels)
+    g = torch.Generator().manual_seed(1234)
+    frames = 0.1 * torch.randn(256, p.n_fft, generator=g)
+    init = torch.rand(256, p.n_stft, 3, dtype=torch.complex64, generator=torch.Generator().manual_seed(4321))
+    out, hx, resid = dn.process_frame(frames.to(dev), None, init_angles=init.to(dev), return_residual=True)
+    idx = torch.arange(0, 256, 16)
+    fb = dsp_ref.melscale_fbanks(p.n_stft, p.n_mels, p.sample_rate)
+    with torch.no_grad():
+        ref = pipeline_ref.process_frame(_state_dict("dari_tult"), frames[idx], torch.zeros(len(idx), 17, 5), p, fb, init_angles=init[idx])
+    e = (resid.cpu()[idx] - ref["predicted_diff"]).numpy()
+    rel = float(np.sqrt(np.mean(e ** 2)) / np.sqrt(np.mean(ref["predicted_diff"].numpy() ** 2)))
+    w = (out.cpu()[idx] - ref["out"]).numpy()
+    w_rms, w_max = float(np.sqrt(np.mean(w ** 2))), float(np.abs(w).max())
+    print(f"bf16 hop: residual rel-RMS {rel:.2e} max-abs {np.abs(e).max():.3f}; waveform RMS {w_rms:.2e} max-abs {w_max:.3f} "
+          f"(ref RMS {float(ref['out'].pow(2).mean().sqrt()):.3f}); hx max-abs {float((hx.cpu()[idx] - ref['hx']).abs().max()):.2e}")
+    assert rel <= 1e-2 and np.abs(e).max() <= 5e-1 and np.abs(e).max() > 1e-5
+    assert w_rms <= 5e-3 and w_max <= 5e-2
+    assert float((hx.cpu()[idx] - ref["hx"]).abs().max()) <= 5e-2
+    # the pipelined hop runs the same bf16 front half: bit-equal to the one-launch hop
+    fd = frames.to(dev)
+    hx_a, hx_b = dn.init_hx(256), dn.init_hx(256)
+    oa, ob = torch.empty(256, p.n_fft, device=dev), torch.empty(256, p.n_fft, device=dev)
+    dn.process_frame_(fd, hx_a, oa, seed=5, stream_id0=0)
+    pipe = HopPipeline(dn, 256)
+    pipe.submit(fd, hx_b, ob, seed=5, stream_id0=0)
+    pipe.flush()
+    torch.cuda.synchronize()
+    assert torch.equal(hx_a, hx_b) and torch.equal(oa, ob)
+    m.conv_precision = "fp32"
+    with pytest.raises(RuntimeError):
+        pipe.submit(fd, hx_b, ob)                  # the precision of a pipe is fixed at creation

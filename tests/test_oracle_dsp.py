@@ -92,3 +92,59 @@ def test_third_opinion_scipy_signal(p):
     _, y = ss.istft(Z / win.sum(), nperseg=p.n_fft, noverlap=p.n_fft - p.hop, window=win, boundary=True, input_onesided=True)
     y_ref = dsp_ref.inverse_spectrogram(torch.from_numpy(s), p.n_fft, p.hop).numpy()
     assert np.abs(y[:, :p.n_fft] - y_ref).max() <= 1e-4
+
+
+def test_real_clip_fixture_is_reproduced_by_the_oracle():
+    """tests/golden/clip_S.npz (BASELINE configs[0]: one 3 s / 16 kHz clip, 93 hops, batch 1) is what the oracle's streaming
+    loop gives today -- the CPU 'plumbing' run of configs[0]; first 12 hops re-run here to keep the CPU tier quick."""
+    from oracle import model_ref
+    from oracle.make_clip_golden import clip_init_angles
+    import os
+    from conftest import GOLDEN
+    p = pipeline_ref.PARAMS_S
+    g = load_golden("clip_S.npz")
+    assert g["signal_s16"].shape == (p.n_fft + p.hop * 92,) and g["out"].shape == (1, 93 * p.hop)
+    sig = torch.from_numpy(g["signal_s16"].astype(np.float32) / np.float32(32767))[None]
+    sd = model_ref.unflatten_weights(np.fromfile(os.path.join(GOLDEN, "weights_dari_tult.bin"), dtype=np.float32))
+    st = pipeline_ref.StreamRef(sd, p, 1)
+    n = 12
+    with torch.no_grad():
+        y = st.push(sig[:, :p.n_fft + p.hop * (n - 1)], init_angles_per_hop=[clip_init_angles(f) for f in range(n)])
+    assert np.abs(y.numpy() - g["out"][:, :n * p.hop]).max() <= 1e-5
+
+
+@pytest.mark.parametrize("p", [pipeline_ref.PARAMS_S, pipeline_ref.PARAMS_R1], ids=["S", "R1"])
+def test_third_opinion_griffinlim_inner_step_and_min_norm_inverse_mel(p):
+    """scipy as the third opinion for the two stages the float64 double-entry check alone covered so far:
+    (1) one Griffin-Lim inner step -- istft of a NON-consistent 3-column spectrogram (random phases on a magnitude), then stft of
+        the result -- through scipy.signal.istft / stft against the restatement of torch.istft / torch.stft;
+    (2) InverseMelScale's lstsq(driver='gels') on the underdetermined system == the minimum-norm solution scipy.linalg.lstsq
+        (gelsd, SVD based) and scipy.linalg.pinv give, at both parameter sets (R1 = the app's own 769 x 64 system)."""
+    import scipy.linalg as sl
+    import scipy.signal as ss
+    g = torch.Generator().manual_seed(21)
+    mag = torch.rand(2, p.n_stft, 3, generator=g) * 5.0
+    ang = torch.rand(2, p.n_stft, 3, dtype=torch.complex64, generator=g)
+    X = (ang * mag)
+    inv = dsp_ref.inverse_spectrogram(X, p.n_fft, p.hop)                  # torch.istft ignores Im X[0], Im X[N/2] (C2R convention)
+    reb = dsp_ref.spectrogram(inv, p.n_fft, p.hop).numpy()
+    win = ss.get_window("hann", p.n_fft, fftbins=True)
+    Xn = X.numpy().astype(np.complex128)
+    Xn[:, 0, :] = Xn[:, 0, :].real
+    Xn[:, -1, :] = Xn[:, -1, :].real
+    _, y = ss.istft(Xn / win.sum(), nperseg=p.n_fft, noverlap=p.n_fft - p.hop, window=win, boundary=True, input_onesided=True)
+    y = y[:, :p.n_fft]
+    assert np.abs(y - inv.numpy()).max() <= 1e-4 * max(1.0, np.abs(y).max())
+    _, _, Z = ss.stft(y, nperseg=p.n_fft, noverlap=p.n_fft - p.hop, window=win, boundary="even", padded=False, return_onesided=True)
+    Z = Z * win.sum()
+    assert Z.shape == reb.shape and np.abs(Z - reb).max() <= 2e-4 * np.abs(Z).max()
+    # (2)
+    fb = dsp_ref.melscale_fbanks(p.n_stft, p.n_mels, p.sample_rate)
+    mel = torch.rand(3, p.n_mels, 3, generator=g) * 20
+    ours = dsp_ref.inverse_mel_scale(mel, fb).numpy()                    # relu(lstsq(fb^T, mel))
+    A = fb.numpy().astype(np.float64).T                                  # (M, K): underdetermined, full row rank
+    for b in range(3):
+        sol, _, rank, _ = sl.lstsq(A, mel[b].numpy().astype(np.float64), lapack_driver="gelsd")
+        assert rank == p.n_mels
+        assert np.abs(np.maximum(sol, 0.0) - ours[b]).max() <= 2e-4
+        assert np.abs(sol - sl.pinv(A) @ mel[b].numpy().astype(np.float64)).max() <= 1e-8
