@@ -25,7 +25,8 @@ SYMBOLS = (
     "dn_dsp_get_tables", "dn_stft", "dn_stft_mel_log1p", "dn_mel_scale", "dn_invmel", "dn_residual_invmel",
     "dn_griffinlim", "dn_synthesis", "dn_istft", "dn_workspace_bytes", "dn_process_frame", "dn_stream_step",
     "dn_pipe_create", "dn_pipe_destroy", "dn_pipe_set_model", "dn_pipe_reserve_parity", "dn_pipe_get_counters", "dn_pipe_submit", "dn_pipe_flush", "dn_pipe_stream_create", "dn_pipe_stream_push",
-    "dn_pipe_stream_flush", "dn_pipe_stream_get_state", "dn_pipe_stream_set_state", "dn_last_error", "dn_abi_version",
+    "dn_pipe_stream_flush", "dn_pipe_stream_get_state", "dn_pipe_stream_set_state", "dn_momo_create", "dn_momo_destroy",
+    "dn_momo_forward", "dn_last_error", "dn_abi_version",
 )
 
 DN_PEAK_NORMALIZE = 1
@@ -37,6 +38,11 @@ ABI_VERSION = 2
 class ModelCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("num_compressed_bins", "in_size", "n_levels", "hidden_size",
                                          "kernel_size", "stride", "padding", "num_gaussians")]
+
+
+class MomoCfg(C.Structure):
+    _fields_ = [("num_compressed_bins", C.c_int32), ("in_size", C.c_int32), ("n_levels", C.c_int32), ("hidden_size", C.c_int32),
+                ("kernel_size", C.c_int32), ("stride", C.c_int32), ("paddings", C.c_int32 * 3), ("num_gaussians", C.c_int32)]
 
 
 class DspCfg(C.Structure):
@@ -72,6 +78,10 @@ class DnLib:
         L.dn_stft_general.argtypes = [vp, p, p, p, i32, i32, vp]
         L.dn_server_rows.argtypes = [vp, p, p, p, p, i32, vp]
         L.dn_istft_general.argtypes = [vp, p, p, i32, i32, vp]
+        L.dn_momo_create.argtypes = [vp, C.c_size_t, C.POINTER(MomoCfg), C.POINTER(vp)]
+        L.dn_momo_destroy.argtypes = [vp]
+        L.dn_momo_destroy.restype = None
+        L.dn_momo_forward.argtypes = [vp, p, p, p, p, p, p, i32, i32, i32, i32, vp]
         L.dn_dsp_create.argtypes = [C.POINTER(DspCfg), vp, vp, vp, C.POINTER(vp)]
         L.dn_dsp_destroy.argtypes = [vp]
         L.dn_dsp_destroy.restype = None

@@ -88,9 +88,12 @@ std::vector<float> linspace01(int n) {
     return v;
 }
 
-// GaussianSmearing table S[g][l], gruunet2.py:54-68 on linspace(0,1,L)
+// GaussianSmearing table S[g][l], gruunet2.py:54-68 on linspace(0,1,L).  The reference fixes `coeff` at construction from its own
+// linspace(0, 1, num_gaussians) (gruunet2.py:62-63) and never recomputes it after load_state_dict: only `dist - offset` uses the
+// loaded buffer.
 std::vector<float> smear_table(const float* offset, int L) {
-    const float diff = offset[1] - offset[0];
+    const std::vector<float> o6 = linspace01(dn::kGauss);
+    const float diff = o6[1] - o6[0];
     const double coeff = -0.5 / ((double)diff * (double)diff);
     const float cf = (float)coeff;
     std::vector<float> pos = linspace01(L), s((size_t)dn::kGauss * L);
@@ -254,6 +257,12 @@ bool chol_solve(std::vector<double>& G, std::vector<double>& R, int n, int m) {
 hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 }  // namespace
+
+// for the other translation units of the library (dn_momo.hip): set the calling thread's error message
+const char* dn_last_error_set(const char* msg) {
+    g_err = msg;
+    return g_err.c_str();
+}
 
 extern "C" {
 

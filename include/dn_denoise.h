@@ -13,6 +13,7 @@
  * Reference interfaces replaced (file:line in belacks/audio-denoising):
  *   dn_model_create / dn_cell_forward   gruunet2.py:246-306  GRUUNet2.__init__/forward
  *                                       (called at app3.py:112-116, 200-201; server.py:151,212)
+ *   dn_momo_create / dn_momo_forward    momo3.py:247-324     MOMO3.__init__/forward (sibling model)
  *   dn_dsp_create                       app3.py:135-155  construction of the torchaudio
  *                                       Spectrogram/MelScale/InverseMelScale/GriffinLim + Hann window
  *   dn_stft                             app3.py:191      Spectrogram(power=None)(x)
@@ -101,6 +102,32 @@ int dn_cell_forward_ex(const dn_model* m, const float* x, const float* hx_in, fl
  * (tests/test_gpu_parity.py: <= 1e-2 relative RMS, <= 5e-1 max-abs on the mel residual; measured 4e-3 / 0.07-0.31). */
 int dn_cell_forward_bf16(const dn_model* m, const float* x, const float* hx_in, float* out, float* hx_out,
                          int32_t B, int32_t T, int32_t F, int32_t C, void* stream);
+
+/* ---- Sibling model MOMO3 (momo3.py:247-324; checkpoint saves/MOMO3-4d4ea0) on the same fp32 MFMA conv tiles -------------
+ * Differences from GRUUNet2: a second input channel, the frame delta x_t - prev (momo3.py:285-289); the position code
+ * enters only at the encoder input and at the hidden-gate conv (momo3.py:138-145); 3 levels, hidden 16, per-level
+ * paddings (1, 0, 1) -- 22 input bins compress to 3.  The kernels are built for that architecture (paddings 0 or 1, up to
+ * 64 input bins); anything else returns DN_ERR_UNSUPPORTED. */
+typedef struct dn_momo dn_momo;
+typedef struct dn_momo_cfg {
+    int32_t num_compressed_bins; /* default hx is zeros(B,16,num_compressed_bins) */
+    int32_t in_size;             /* 1 (the delta channel is added internally, momo3.py:260) */
+    int32_t n_levels;            /* 3 */
+    int32_t hidden_size;         /* 16 */
+    int32_t kernel_size;         /* 3 */
+    int32_t stride;              /* 2 */
+    int32_t paddings[3];         /* (1, 0, 1) in the checkpoint */
+    int32_t num_gaussians;       /* 6 */
+} dn_momo_cfg;
+#define DN_MOMO3_N_FLOATS 9197   /* state_dict order of momo3.MOMO3 */
+int dn_momo_create(const float* weights, size_t n_floats, const dn_momo_cfg* cfg, dn_momo** out);
+void dn_momo_destroy(dn_momo* m);
+/* MOMO3.forward for B streams, T sequential steps: x [dev][B][T][F], hx_in [dev][B][16][C] (NULL = zeros), prev_in [dev][B][F]
+ * (the frame before x[:,0]; NULL = the first delta is zero, momo3.py:277-278), out [dev][B][T][F], hx_out [dev][B][16][C],
+ * prev_out [dev][B][F] or NULL (the last frame: what the caller passes as prev_in to continue the sequence).  C must be what F
+ * compresses to under the model's paddings (else DN_ERR_INVALID, mirroring the reference's broadcast error). */
+int dn_momo_forward(const dn_momo* m, const float* x, const float* hx_in, const float* prev_in, float* out, float* hx_out,
+                    float* prev_out, int32_t B, int32_t T, int32_t F, int32_t C, void* stream);
 
 typedef struct dn_dsp_cfg {
     int32_t sample_rate;

@@ -337,3 +337,26 @@ def test_server_variant_matches_oracle(lib):
         assert np.sqrt(np.mean((wave - g["out"][c]) ** 2)) <= 1e-3 * max(1.0, np.sqrt(np.mean(g["out"][c] ** 2)))
     lib.dn_model_destroy(m)
     lib.dn_dsp_destroy(d)
+
+
+# ------------------------------------------------------------------ sibling model MOMO3 on the general conv tiles
+@pytest.mark.parametrize("name", ["momo3_B4_T3_F22.npz", "momo3_B3_T7_F24.npz", "momo3_B2_T1_F23.npz"])
+def test_momo3_matches_reference_golden(lib, name):
+    from audio_denoising_amd._lib import MomoCfg
+    g = load_golden(name)
+    B, T, F = g["x"].shape
+    Cb = g["hx0"].shape[2]
+    w = np.fromfile(os.path.join(GOLDEN, "weights_momo3_4d4ea0.bin"), dtype=np.float32)
+    h = C.c_void_p()
+    lib.check(lib.dn_momo_create(emu.ptr(w), w.size, C.byref(MomoCfg(Cb, 1, 3, 16, 3, 2, (C.c_int32 * 3)(1, 0, 1), 6)), C.byref(h)))
+    out = np.zeros((B, T, F), np.float32)
+    hx1 = np.zeros((B, 16, Cb), np.float32)
+    last = np.zeros((B, F), np.float32)
+    prev = emu.f32(g["prev"].reshape(B, F)) if "prev" in g.files else None
+    lib.check(lib.dn_momo_forward(h, emu.ptr(emu.f32(g["x"])), emu.ptr(emu.f32(g["hx0"])), emu.ptr(prev), emu.ptr(out), emu.ptr(hx1),
+                                  emu.ptr(last), B, T, F, Cb, None))
+    assert np.abs(out - g["out"]).max() <= 1e-4 and np.abs(hx1 - g["hx1"]).max() <= 1e-4
+    assert np.array_equal(last, g["x"][:, -1, :])
+    rc = lib.dn_momo_forward(h, emu.ptr(emu.f32(g["x"])), emu.ptr(emu.f32(g["hx0"])), None, emu.ptr(out), emu.ptr(hx1), None, B, T, F, Cb + 1, None)
+    assert rc == -1 and b"compress" in lib.dn_last_error()
+    lib.dn_momo_destroy(h)

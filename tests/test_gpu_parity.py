@@ -788,3 +788,48 @@ def test_config3_bf16_conv_tiles_inside_the_whole_hop_batch256(dev):
     m.conv_precision = "fp32"
     with pytest.raises(RuntimeError):
         pipe.submit(fd, hx_b, ob)                  # the precision of a pipe is fixed at creation
+
+
+# ------------------------------------------------------------------ sibling model MOMO3
+MOMO_CFG = dict(num_compressed_bins=3, in_size=1, hidden_sizes=(16, 16, 16), kernel_sizes=(3, 3, 3), strides=(2, 2, 2), paddings=(1, 0, 1), num_gaussians=6)
+
+
+def _momo(dev, C=3):
+    from momo3 import MOMO3                  # the reference's import line for this model
+    from oracle import momo_ref
+    m = MOMO3(**dict(MOMO_CFG, num_compressed_bins=C))
+    m.load_state_dict(momo_ref.unflatten_weights(np.fromfile(os.path.join(GOLDEN, "weights_momo3_4d4ea0.bin"), dtype=np.float32)))
+    return m.eval().to(dev)
+
+
+@pytest.mark.parametrize("name", sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "momo3_B*_T*_F*.npz"))))
+def test_momo3_forward_matches_reference_golden(dev, name):
+    """MOMO3 (frame-delta channel, position code at the input only, paddings (1,0,1): 22 -> 11 -> 5 -> 3) on the general fp32 MFMA
+    conv tiles against vectors from the reference's own class, incl. batch 256 and a case that continues a sequence (prev given)."""
+    g = load_golden(name)
+    m = _momo(dev, g["hx0"].shape[2])
+    prev = torch.from_numpy(g["prev"]).to(dev) if "prev" in g.files else None
+    with torch.no_grad():
+        out, hx = m(torch.from_numpy(g["x"]).to(dev), torch.from_numpy(g["hx0"]).to(dev), prev=prev)
+    assert out.shape == g["out"].shape and hx.shape == g["hx1"].shape
+    assert np.abs(out.cpu().numpy() - g["out"]).max() <= TOL_RESIDUAL
+    assert np.abs(hx.cpu().numpy() - g["hx1"]).max() <= TOL_RESIDUAL
+
+
+def test_momo3_conventions_chain_and_errors(dev):
+    g = load_golden("momo3_conventions.npz")
+    m = _momo(dev)
+    o2, h2 = m(torch.from_numpy(g["x2"]).to(dev))                     # (T,F) input, hx=None (momo3.py:301-316)
+    assert o2.shape == (3, 22) and h2.shape == (1, 16, 3)
+    assert np.abs(o2.cpu().numpy() - g["out2"]).max() <= TOL_RESIDUAL
+    hx, prev = None, None
+    for h in range(12):                                               # hx and prev carried by the caller, as the reference's API has it
+        x = torch.from_numpy(g["xs"][h]).to(dev)
+        o, hx = m(x, hx, prev=prev)
+        prev = m.last_frame(x)
+        assert np.abs(o.cpu().numpy() - g["outs"][h]).max() <= TOL_RESIDUAL
+    assert np.abs(hx.cpu().numpy() - g["hx_final"]).max() <= TOL_RESIDUAL
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 3, 44, device=dev))                          # 44 bins compress to 5, hx default has 3: shape error as in the reference
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 3, 22))                                      # CPU tensor: no fallback

@@ -61,3 +61,42 @@ def test_smear_tables_match_reference():
     off = torch.linspace(0, 1, 6)
     for L in (80, 64, 40, 32, 20, 16, 10, 8, 5, 4):
         assert np.abs(model_ref.smear_table(off, L).numpy() - g[f"L{L}"]).max() <= 1e-7
+
+
+# ------------------------------------------------------------------ sibling model MOMO3
+MOMO_CASES = ["momo3_B1_T3_F22.npz", "momo3_B4_T3_F22.npz", "momo3_B256_T3_F22.npz", "momo3_B3_T7_F24.npz", "momo3_B2_T1_F23.npz"]
+
+
+def _momo_sd():
+    import os
+    from conftest import GOLDEN
+    from oracle import momo_ref
+    return momo_ref.unflatten_weights(np.fromfile(os.path.join(GOLDEN, "weights_momo3_4d4ea0.bin"), dtype=np.float32))
+
+
+@pytest.mark.parametrize("name", MOMO_CASES)
+def test_momo3_restatement_matches_reference_golden(name):
+    """oracle/momo_ref.py against vectors produced by the reference's own momo3.MOMO3 (oracle/make_momo_golden.py): PINNED."""
+    from oracle import momo_ref
+    g = load_golden(name)
+    prev = torch.from_numpy(g["prev"]) if "prev" in g.files else None
+    with torch.no_grad():
+        out, hx = momo_ref.forward(_momo_sd(), torch.from_numpy(g["x"]), torch.from_numpy(g["hx0"]), prev)
+    assert np.abs(out.numpy() - g["out"]).max() <= 1e-5 and np.abs(hx.numpy() - g["hx1"]).max() <= 1e-5
+
+
+def test_momo3_conventions_and_carried_prev():
+    from oracle import momo_ref
+    g = load_golden("momo3_conventions.npz")
+    sd = _momo_sd()
+    with torch.no_grad():
+        o2, h2 = momo_ref.forward(sd, torch.from_numpy(g["x2"]))             # (T,F) input, hx=None
+        assert o2.shape == (3, 22) and h2.shape == (1, 16, 3)
+        assert np.abs(o2.numpy() - g["out2"]).max() <= 1e-5
+        hx, prev = None, None
+        for h in range(12):
+            x = torch.from_numpy(g["xs"][h])
+            o, hx = momo_ref.forward(sd, x, hx, prev)
+            prev = x[:, -1:, :].clone()
+            assert np.abs(o.numpy() - g["outs"][h]).max() <= 1e-5
+    assert np.abs(hx.numpy() - g["hx_final"]).max() <= 1e-5
