@@ -297,18 +297,21 @@ int dn_model_create(const float* weights, size_t n_floats, const dn_model_cfg* c
                 }
         m->off_down[l] = m->packed.add(p.data(), p.size() * sizeof(float));
     }
-    {
-        std::vector<float> p((size_t)17 * 3 * 51);
-        for (int c = 0; c < 17; ++c)
-            for (int k = 0; k < 3; ++k)
-                for (int o = 0; o < 51; ++o) p[((size_t)c * 3 + k) * 51 + o] = W[sl.gw + ((size_t)o * 23 + c) * 3 + k];
+    {   // hidden-gate conv (51, 17 data channels, 3) as A fragments too: [mt 4][ks 13][64], K slot = 3 c + tap (51 slots + 1 zero)
+        std::vector<float> p((size_t)4 * 13 * 64, 0.0f);
+        for (int mt = 0; mt < 4; ++mt)
+            for (int ks = 0; ks < 13; ++ks)
+                for (int ln = 0; ln < 64; ++ln) {
+                    const int o = mt * 16 + (ln & 15), kk = 4 * ks + (ln >> 4), c = kk / 3, k = kk % 3;
+                    if (o < 51 && c < 17) p[((size_t)mt * 13 + ks) * 64 + ln] = W[sl.gw + ((size_t)o * 23 + c) * 3 + k];
+                }
         m->off_gh = m->packed.add(p.data(), p.size() * sizeof(float));
     }
-    for (int l = 0; l < 3; ++l) {   // ConvTranspose1d weight (Ct, Cout, 3) -> [mt][tap set: k=1,k=2,k=0][ks][64], parts of 17 channels in fours
-        const int parts = l == 0 ? 1 : 2, co = 17, ksu = parts * 5;
+    for (int l = 0; l < 4; ++l) {   // ConvTranspose1d weight (Ct, Cout, 3) -> [mt][tap set: k=1,k=2,k=0][ks][64], parts of 17 channels in fours
+        const int parts = l == 0 ? 1 : 2, co = l == 3 ? 1 : 17, ksu = parts * 5, mtiles = (co + 15) / 16;   // last level: one channel = one row tile
         static const int kTapOfSet[3] = {1, 2, 0};
-        std::vector<float> p((size_t)2 * 3 * ksu * 64, 0.0f);
-        for (int mt = 0; mt < 2; ++mt)
+        std::vector<float> p((size_t)mtiles * 3 * ksu * 64, 0.0f);
+        for (int mt = 0; mt < mtiles; ++mt)
             for (int set = 0; set < 3; ++set)
                 for (int ks = 0; ks < ksu; ++ks)
                     for (int ln = 0; ln < 64; ++ln) {
@@ -317,12 +320,6 @@ int dn_model_create(const float* weights, size_t n_floats, const dn_model_cfg* c
                             p[(((size_t)mt * 3 + set) * ksu + ks) * 64 + ln] = W[sl.uw[l] + ((size_t)c * co + o) * 3 + kTapOfSet[set]];
                     }
         m->off_up[l] = m->packed.add(p.data(), p.size() * sizeof(float));
-    }
-    {   // last decoder level (one output channel): [c][k], read through the scalar cache
-        std::vector<float> p((size_t)34 * 3);
-        for (int c = 0; c < 34; ++c)
-            for (int k = 0; k < 3; ++k) p[(size_t)c * 3 + k] = W[sl.uw[3] + (size_t)c * 3 + k];
-        m->off_up[3] = m->packed.add(p.data(), p.size() * sizeof(float));
     }
     // bf16 fragments for v_mfma_f32_16x16x32_bf16 (config 3): lane l of k-step ks supplies 8 consecutive K slots
     // 8 (l >> 4) + j = channels of one tap (level 0: the taps themselves); round to nearest even.

@@ -29,11 +29,12 @@ namespace dn {
 
 constexpr int kCellWaves = 4;
 
+template <int CT>
 __global__ __launch_bounds__(kCellWaves * 64) void cell_kernel(CellDev cd, const float* __restrict__ x,
                                                               const float* __restrict__ hx_in, float* __restrict__ out,
                                                               float* __restrict__ hx_out, int T, int C) {
     __shared__ __attribute__((aligned(16))) char smem[kCellSmem];
-    cell_body<kCellWaves>(smem, cd, x, hx_in, out, hx_out, T, C, blockIdx.x, threadIdx.x);
+    cell_body<kCellWaves, false, CT>(smem, cd, x, hx_in, out, hx_out, T, C, blockIdx.x, threadIdx.x);
 }
 
 // BASELINE config 3: the same forward with bf16 MFMA conv tiles (v_mfma_f32_16x16x32_bf16; conv inputs and weights
@@ -47,7 +48,9 @@ __global__ __launch_bounds__(kCellWaves * 64) void cell_kernel_bf16(CellDev cd, 
 
 void launch_cell(const CellDev& c, const float* x, const float* hx_in, float* out, float* hx_out, int B, int T,
                  int C, hipStream_t st) {
-    hipLaunchKernelGGL(cell_kernel, dim3(B), dim3(kCellWaves * 64), 0, st, c, x, hx_in, out, hx_out, T, C);
+    if (C == 5) hipLaunchKernelGGL(cell_kernel<5>, dim3(B), dim3(kCellWaves * 64), 0, st, c, x, hx_in, out, hx_out, T, C);
+    else if (C == 4) hipLaunchKernelGGL(cell_kernel<4>, dim3(B), dim3(kCellWaves * 64), 0, st, c, x, hx_in, out, hx_out, T, C);
+    else hipLaunchKernelGGL(cell_kernel<0>, dim3(B), dim3(kCellWaves * 64), 0, st, c, x, hx_in, out, hx_out, T, C);
 }
 
 __global__ __launch_bounds__(kCellWaves * 64) void cell_kernel_ex(CellDev cd, const float* __restrict__ x,
@@ -68,3 +71,10 @@ void launch_cell_bf16(const CellDev& c, const float* x, const float* hx_in, floa
 }
 
 }  // namespace dn
+
+#ifdef DN_PROBE
+// diagnostic build only: the phase stamps of workgroup 0 of the stand-alone cell kernel
+extern "C" int dn_probe_read_cell(unsigned long long* host32) {
+    return (int)hipMemcpyFromSymbol(host32, HIP_SYMBOL(dn::g_cell_probe), sizeof(dn::g_cell_probe));
+}
+#endif

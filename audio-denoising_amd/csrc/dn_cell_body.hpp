@@ -6,10 +6,20 @@
 
 namespace dn {
 
-
-__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
+// Diagnostic build only (make probe): s_memtime stamps of the phases of one forward of workgroup 0 (tools/cell_probe.py).
+#ifdef DN_PROBE
+static __device__ unsigned long long g_cell_probe[32];
+#define DN_CSTAMP(id)                                                                             \
+    do {                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        unsigned long long t_;                                                                    \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
+        if (b == 0 && tid == 0) g_cell_probe[id] = t_;                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+    } while (0)
+#else
+#define DN_CSTAMP(id) do { } while (0)
+#endif
 
 // ---- Conv1d k3 s2 p1 (+ folded position bias, relu) as an MFMA contraction.
 //   in [TT][CIN][2*lout] (LDS) -> out [TT][COUT][lout] (LDS)
@@ -17,7 +27,7 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 //          (CIN = 1: one k-step whose 4 K slots are the 3 taps + a zero)
 //   work split: tile = (n-tile of 16 items) x (group of MT m-tiles); tiles are dealt to waves round robin.
 template <int NW, int CIN, int COUT, int MT>
-__device__ __forceinline__ void mconv_down(const float* __restrict__ afrag, const float* __restrict__ bt, const float* in,
+__device__ __forceinline__ void mconv_down(const float* afrag, const float* bt, const float* in,
                                            float* out, int lout, int tt, int wv, int lane) {
     constexpr int CS = (CIN + 3) / 4;
     constexpr int KS = CIN == 1 ? 1 : 3 * CS;
@@ -80,7 +90,7 @@ __device__ __forceinline__ f32x4 mfma16_bf16(const bf16x8& a, const bf16x8& b, f
 }
 
 template <int NW, int CIN, int COUT, int MT>
-__device__ __forceinline__ void mconv_down_bf16(const void* __restrict__ afrag, const float* __restrict__ bt, const float* in,
+__device__ __forceinline__ void mconv_down_bf16(const void* afrag, const float* bt, const float* in,
                                                 float* out, int lout, int tt, int wv, int lane) {
     constexpr int KS = CIN == 1 ? 1 : 3;
     constexpr int MTILES = (COUT + 15) / 16;
@@ -140,7 +150,7 @@ __device__ __forceinline__ void mconv_down_bf16(const void* __restrict__ afrag, 
 }
 
 template <int NW, bool SKIP, int MT>
-__device__ __forceinline__ void mconv_up_bf16(const void* __restrict__ afrag, const float* __restrict__ bt, const float* a,
+__device__ __forceinline__ void mconv_up_bf16(const void* afrag, const float* bt, const float* a,
                                               const float* skip, float* out, int l, int tt, int wv, int lane) {
     constexpr int PARTS = SKIP ? 2 : 1;
     constexpr int MTILES = 2, MG = MTILES / MT;
@@ -202,12 +212,12 @@ __device__ __forceinline__ void mconv_up_bf16(const void* __restrict__ afrag, co
 // Item = (t, input position i):  out[2i]   = sum_c w[c][o][1] x[c][i]
 //                                out[2i+1] = sum_c w[c][o][2] x[c][i] + w[c][o][0] x[c][i+1]
 // afrag: [MTILES=2][3 tap sets: k=1, k=2, k=0][KSU][64]; K order = part-major (a, then skip), channels in fours.
-template <int NW, bool SKIP, int MT>
-__device__ __forceinline__ void mconv_up(const float* __restrict__ afrag, const float* __restrict__ bt, const float* a,
-                                         const float* skip, float* out, int l, int tt, int wv, int lane) {
+template <int NW, bool SKIP, int MT, int COUT = kHidden, bool LAST = false>
+__device__ __forceinline__ void mconv_up(const float* afrag, const float* bt, const float* a,
+                                         const float* skip, float* out, int l, int tt, int wv, int lane, size_t out_t_stride = 0) {
     constexpr int CS = 5;                      // ceil(17 / 4)
     constexpr int KSU = SKIP ? 2 * CS : CS;
-    constexpr int MTILES = 2, MG = MTILES / MT;
+    constexpr int MTILES = (COUT + 15) / 16, MG = MTILES / MT;
     const int lo = 2 * l, items = tt * l, ntiles = (items + 15) >> 4;
     const int q = lane >> 4, jl = lane & 15;
     for (int tile = wv; tile < ntiles * MG; tile += NW) {
@@ -223,8 +233,8 @@ __device__ __forceinline__ void mconv_up(const float* __restrict__ afrag, const 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int o = (mt0 + mi) * 16 + q * 4 + r;
-                ev[mi][r] = o < kHidden ? bt[o * lo + 2 * i] : 0.0f;
-                od[mi][r] = o < kHidden ? bt[o * lo + 2 * i + 1] : 0.0f;
+                ev[mi][r] = o < COUT ? bt[o * lo + 2 * i] : 0.0f;
+                od[mi][r] = o < COUT ? bt[o * lo + 2 * i + 1] : 0.0f;
             }
         const float* af = afrag + (size_t)mt0 * 3 * KSU * 64 + lane;
 #pragma unroll
@@ -251,9 +261,13 @@ __device__ __forceinline__ void mconv_up(const float* __restrict__ afrag, const 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int o = (mt0 + mi) * 16 + q * 4 + r;
-                    if (o < kHidden)
-                        *reinterpret_cast<float2*>(out + ((size_t)t * kHidden + o) * lo + 2 * i) =
-                            make_float2(fmaxf(ev[mi][r], 0.0f), fmaxf(od[mi][r], 0.0f));
+                    if (o < COUT) {
+                        if (LAST)      // the last level is linear and its single channel is the model output row (gruunet2.py:94-96, 242)
+                            *reinterpret_cast<float2*>(out + (size_t)t * out_t_stride + 2 * i) = make_float2(ev[mi][r], od[mi][r]);
+                        else
+                            *reinterpret_cast<float2*>(out + ((size_t)t * COUT + o) * lo + 2 * i) =
+                                make_float2(fmaxf(ev[mi][r], 0.0f), fmaxf(od[mi][r], 0.0f));
+                    }
                 }
         }
     }
@@ -282,17 +296,63 @@ struct CellLds {
     }
 };
 
-constexpr int kCellLdsFloats = 4 + 3 * 16 * kMaxC + 3 * 17 * 14 * kMaxC * 2 + 3 * 51 * kMaxC + 17 * kMaxC + 51 * kMaxC + 3 * 17 * kMaxC;
-constexpr int kCellSmem = 4 * kCellLdsFloats;      // 34,976 B
+constexpr int kCellActFloats = 4 + 3 * 16 * kMaxC + 3 * 17 * 14 * kMaxC * 2 + 3 * 51 * kMaxC + 17 * kMaxC + 51 * kMaxC + 3 * 17 * kMaxC;
+// Weight fragments and bias tables are staged through LDS one level ahead (double buffered): while level L multiplies, every
+// thread has level L+1's share of fragments in flight from L2 and drops it into the other buffer before the barrier.  The
+// levels are a strictly serial chain of short phases (~1 us each): with the fragments fetched at the head of every phase the
+// kernel spent 71 % of its time in s_waitcnt (profiles/r01_v4_pmc_sq.txt); staged, a phase starts on LDS-resident operands.
+constexpr int kCellWFloats = 4 * 15 * 64;        // largest level: 51 -> 4 row tiles x 15 k-steps (= 2 x 3 x 10 of a skip decoder level)
+constexpr int kCellBFloats = kHidden * 8 * kMaxC;  // largest bias table: 17 channels x 8C positions
+constexpr int kCellLdsFloats = kCellActFloats + 2 * kCellWFloats + 2 * kCellBFloats;
+constexpr int kCellSmem = 4 * kCellLdsFloats;      // 71,136 B
+
+// One level's operands in HBM/L2: weight fragments (fp32 or bf16, counted in floats) and the bias table.
+struct CellLevel { const float* w; int wn; const float* b; int bn; };
+
+template <int THREADS>
+struct CellStager {
+    static constexpr int kW4 = (kCellWFloats / 4 + THREADS - 1) / THREADS;     // float4 per thread (5 at 192 threads)
+    static constexpr int kB1 = (kCellBFloats + THREADS - 1) / THREADS;         // floats per thread (4)
+    float4 w[kW4];
+    float b[kB1];
+    __device__ __forceinline__ void issue(const CellLevel& lv, int tid) {
+        const float4* w4 = reinterpret_cast<const float4*>(lv.w);
+#pragma unroll
+        for (int i = 0; i < kW4; ++i) {
+            const int j = tid + THREADS * i;
+            w[i] = 4 * j < lv.wn ? w4[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < kB1; ++i) {
+            const int j = tid + THREADS * i;
+            b[i] = j < lv.bn ? lv.b[j] : 0.0f;
+        }
+    }
+    __device__ __forceinline__ void commit(const CellLevel& lv, float* wbuf, float* bbuf, int tid) const {
+#pragma unroll
+        for (int i = 0; i < kW4; ++i) {
+            const int j = tid + THREADS * i;
+            if (4 * j < lv.wn) reinterpret_cast<float4*>(wbuf)[j] = w[i];
+        }
+#pragma unroll
+        for (int i = 0; i < kB1; ++i) {
+            const int j = tid + THREADS * i;
+            if (j < lv.bn) bbuf[j] = b[i];
+        }
+    }
+};
 
 // One workgroup of NW wavefronts runs the T-step forward of stream `b`.  `smem`: kCellSmem bytes of LDS.
-template <int NW, bool BF16 = false>
+// CT = the number of compressed bins when it is known at compile time (5: 80 mels, 4: 64 mels), 0 = use the run-time value.
+// With CT every length, stride and item/length division of the conv tiles is a constant: the per-k-step address arithmetic
+// (which, not the MFMAs, was what a phase spent its issue slots on) folds into immediate LDS offsets.
+template <int NW, bool BF16 = false, int CT = 0>
 __device__ __forceinline__ void cell_body(char* smem, const CellDev& cd, const float* __restrict__ x,
                                           const float* __restrict__ hx_in, float* __restrict__ out,
-                                          float* __restrict__ hx_out, int T, int C, size_t b, int tid,
+                                          float* __restrict__ hx_out, int T, int C_rt, size_t b, int tid,
                                           float hx_scale = 1.0f) {
     constexpr int kCellThreads = NW * 64;
-    constexpr int kGateSlots = (kGates * kMaxC + kCellThreads - 1) / kCellThreads;   // gate items per thread
+    const int C = CT ? CT : C_rt;
     float* lds = reinterpret_cast<float*>(smem);
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -301,72 +361,138 @@ __device__ __forceinline__ void cell_body(char* smem, const CellDev& cd, const f
     float* sx = lds + L.x;   float* sd0 = lds + L.d0; float* sd1 = lds + L.d1; float* sd2 = lds + L.d2;
     float* sd3 = lds + L.d3; float* sh = lds + L.h;   float* sgh = lds + L.gh; float* shi = lds + L.hi;
     float* su0 = lds + L.u0; float* su1 = lds + L.u1; float* su2 = lds + L.u2;
+    float* wbuf[2] = {lds + kCellActFloats, lds + kCellActFloats + kCellWFloats};
+    float* bbuf[2] = {lds + kCellActFloats + 2 * kCellWFloats, lds + kCellActFloats + 2 * kCellWFloats + kCellBFloats};
 
+    // the eight conv levels in execution order: encoder 0..3, decoder 0..3 (fragment sizes in floats; bf16 fragments are 16 B per lane)
+    auto level = [&](int i) -> CellLevel {
+        CellLevel lv;
+        if (i < 4) {
+            const int mt = i == 3 ? 4 : 2, ks32 = i == 0 ? 1 : 15, ks16 = i == 0 ? 1 : 3;
+            lv.w = BF16 ? static_cast<const float*>(cd.wb_down[i]) : cd.w_down[i];
+            lv.wn = BF16 ? mt * ks16 * 64 * 4 : mt * ks32 * 64;
+            lv.b = cd.bt_down[i];
+            lv.bn = (i == 3 ? kGates : kHidden) * (8 * C >> i);
+        } else {
+            const int l = i - 4, parts = l == 0 ? 1 : 2;
+            const bool bf = BF16 && l < 3;                        // the single-channel last level stays fp32
+            lv.w = bf ? static_cast<const float*>(cd.wb_up[l]) : cd.w_up[l];
+            lv.wn = bf ? 2 * 3 * parts * 64 * 4 : (l == 3 ? 1 : 2) * 3 * parts * 5 * 64;
+            lv.b = cd.bt_up[l];
+            lv.bn = (l == 3 ? 1 : kHidden) * (2 * C << l);
+        }
+        return lv;
+    };
+    // two register sets: level L+2 is requested while level L multiplies and level L+1 (requested a phase earlier) is dropped
+    // into its buffer -- every request has more than a whole phase to come back from L2
+    CellStager<kCellThreads> stgA, stgB;
+    stgA.issue(level(0), tid);
+    stgB.issue(level(1), tid);
+
+    DN_CSTAMP(0);
     if (tid < 4) lds[tid] = 0.0f;
     // hidden state -> LDS (gruunet2.py:294-301: zeros when the caller passes none)
     for (int i = tid; i < kHidden * C; i += kCellThreads) sh[i] = hx_in != nullptr ? hx_in[b * kHidden * C + i] : 0.0f;
 
-    // bottleneck mapping: thread <-> (gate channel o, position p) items tid, tid + threads, ..; the 51 recurrent
-    // weights of each owned item stay in VGPRs across time steps
-    const int gate_items = kGates * C;
-    int g_p[kGateSlots];
-    bool g_on[kGateSlots];
-    float wgh[kGateSlots][kHidden * 3], bgh[kGateSlots];
+    // hidden-gate conv gh = relu(conv k3 s1 p1 (hx) + position bias): rows = 51 gate channels in four row tiles dealt to the
+    // waves, columns = the C positions, K = (channel, tap).  Its fragments and bias are requested here, last in the prologue
+    // (they are not needed before the encoder is through and the LDS-only barriers below let them arrive meanwhile), and
+    // stay in VGPRs for every time step.
+    constexpr int kGhKS = 13, kGhTiles = (4 + NW - 1) / NW;
+    float agh[kGhTiles][kGhKS];
+    f32x4 bgh[kGhTiles];
+    float xin[(kCellChunk * 16 * kMaxC + kCellThreads - 1) / kCellThreads];
+    constexpr int kXR = (kCellChunk * 16 * kMaxC + kCellThreads - 1) / kCellThreads;
+    {
+        const int tt0 = min(kCellChunk, T);
 #pragma unroll
-    for (int sl = 0; sl < kGateSlots; ++sl) {
-        const int gi = tid + sl * kCellThreads;
-        const int g_o = gi / C;
-        g_p[sl] = gi - g_o * C;
-        g_on[sl] = gi < gate_items;
+        for (int r = 0; r < kXR; ++r) {
+            const int i = tid + kCellThreads * r;
+            xin[r] = i < tt0 * F ? x[(b * T) * F + i] : 0.0f;
+        }
+    }
+    {
+        const int q = lane >> 4, p = lane & 15;
 #pragma unroll
-        for (int i = 0; i < kHidden * 3; ++i) wgh[sl][i] = g_on[sl] ? cd.w_gh[i * kGates + g_o] : 0.0f;
-        bgh[sl] = g_on[sl] ? cd.bt_gh[g_o * C + g_p[sl]] : 0.0f;
+        for (int g = 0; g < kGhTiles; ++g) {
+            const int mt = wv + NW * g;                                  // wave-uniform
+#pragma unroll
+            for (int ks = 0; ks < kGhKS; ++ks) agh[g][ks] = mt < 4 ? cd.w_gh[((size_t)mt * kGhKS + ks) * 64 + lane] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = mt * 16 + 4 * q + r;
+                bgh[g][r] = (mt < 4 && o < kGates && p < C) ? cd.bt_gh[o * C + p] : 0.0f;
+            }
+        }
     }
 
     for (int t0 = 0; t0 < T; t0 += kCellChunk) {
         const int tt = min(kCellChunk, T - t0);
-        __syncthreads();
-        for (int i = tid; i < tt * F; i += kCellThreads) sx[i] = x[(b * T + t0) * F + i];
-        __syncthreads();
-        // ---- encoder, batched over the chunk (gruunet2.py:136-144)
-        if (BF16) {
-            mconv_down_bf16<NW, 1, kHidden, 2>(cd.wb_down[0], cd.bt_down[0], sx, sd0, 8 * C, tt, wv, lane);
-            __syncthreads();
-            mconv_down_bf16<NW, kHidden, kHidden, 2>(cd.wb_down[1], cd.bt_down[1], sd0, sd1, 4 * C, tt, wv, lane);
-            __syncthreads();
-            mconv_down_bf16<NW, kHidden, kHidden, 1>(cd.wb_down[2], cd.bt_down[2], sd1, sd2, 2 * C, tt, wv, lane);
-            __syncthreads();
-            mconv_down_bf16<NW, kHidden, kGates, 1>(cd.wb_down[3], cd.bt_down[3], sd2, sd3, C, tt, wv, lane);
-        } else {
-            mconv_down<NW, 1, kHidden, 2>(cd.w_down[0], cd.bt_down[0], sx, sd0, 8 * C, tt, wv, lane);
-            __syncthreads();
-            mconv_down<NW, kHidden, kHidden, 2>(cd.w_down[1], cd.bt_down[1], sd0, sd1, 4 * C, tt, wv, lane);
-            __syncthreads();
-            mconv_down<NW, kHidden, kHidden, 1>(cd.w_down[2], cd.bt_down[2], sd1, sd2, 2 * C, tt, wv, lane);
-            __syncthreads();
-            mconv_down<NW, kHidden, kGates, 1>(cd.w_down[3], cd.bt_down[3], sd2, sd3, C, tt, wv, lane);
+        DN_LDS_BARRIER();
+        if (t0 > 0) {
+#pragma unroll
+            for (int r = 0; r < kXR; ++r) {
+                const int i = tid + kCellThreads * r;
+                xin[r] = i < tt * F ? x[(b * T + t0) * F + i] : 0.0f;
+            }
         }
-        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < kXR; ++r) {
+            const int i = tid + kCellThreads * r;
+            if (i < tt * F) sx[i] = xin[r];
+        }
+        stgA.commit(level(0), wbuf[0], bbuf[0], tid);
+        DN_LDS_BARRIER();
+        DN_CSTAMP(1);
+        // ---- encoder, batched over the chunk (gruunet2.py:136-144); level i multiplies out of buffer i & 1
+        stgA.issue(level(2), tid);
+        if (BF16) mconv_down_bf16<NW, 1, kHidden, 2>(wbuf[0], bbuf[0], sx, sd0, 8 * C, tt, wv, lane);
+        else mconv_down<NW, 1, kHidden, 2>(wbuf[0], bbuf[0], sx, sd0, 8 * C, tt, wv, lane);
+        stgB.commit(level(1), wbuf[1], bbuf[1], tid);
+        DN_LDS_BARRIER();
+        DN_CSTAMP(2);
+        stgB.issue(level(3), tid);
+        if (BF16) mconv_down_bf16<NW, kHidden, kHidden, 2>(wbuf[1], bbuf[1], sd0, sd1, 4 * C, tt, wv, lane);
+        else mconv_down<NW, kHidden, kHidden, 2>(wbuf[1], bbuf[1], sd0, sd1, 4 * C, tt, wv, lane);
+        stgA.commit(level(2), wbuf[0], bbuf[0], tid);
+        DN_LDS_BARRIER();
+        DN_CSTAMP(3);
+        stgA.issue(level(4), tid);
+        if (BF16) mconv_down_bf16<NW, kHidden, kHidden, 1>(wbuf[0], bbuf[0], sd1, sd2, 2 * C, tt, wv, lane);
+        else mconv_down<NW, kHidden, kHidden, 1>(wbuf[0], bbuf[0], sd1, sd2, 2 * C, tt, wv, lane);
+        stgB.commit(level(3), wbuf[1], bbuf[1], tid);
+        DN_LDS_BARRIER();
+        DN_CSTAMP(4);
+        stgB.issue(level(5), tid);
+        if (BF16) mconv_down_bf16<NW, kHidden, kGates, 1>(wbuf[1], bbuf[1], sd2, sd3, C, tt, wv, lane);
+        else mconv_down<NW, kHidden, kGates, 1>(wbuf[1], bbuf[1], sd2, sd3, C, tt, wv, lane);
+        stgA.commit(level(4), wbuf[0], bbuf[0], tid);
+        DN_LDS_BARRIER();
+        DN_CSTAMP(5);
         // ---- recurrent part, sequential in t (gruunet2.py:232-240)
         for (int t = 0; t < tt; ++t) {
+            {
+                const int q = lane >> 4, p = lane & 15;
+                f32x4 acc[kGhTiles];
 #pragma unroll
-            for (int sl = 0; sl < kGateSlots; ++sl) {
-                if (g_on[sl]) {            // gh = relu(conv k3 s1 p1 (hx) + position bias)
-                    float acc = bgh[sl];
+                for (int g = 0; g < kGhTiles; ++g) acc[g] = bgh[g];
 #pragma unroll
-                    for (int c = 0; c < kHidden; ++c) {
-                        const float* hc = sh + c * C + g_p[sl];
-                        const float x0 = g_p[sl] > 0 ? hc[-1] : 0.0f;
-                        const float x1 = hc[0];
-                        const float x2 = g_p[sl] + 1 < C ? hc[1] : 0.0f;
-                        acc = fmaf(wgh[sl][c * 3 + 0], x0, acc);
-                        acc = fmaf(wgh[sl][c * 3 + 1], x1, acc);
-                        acc = fmaf(wgh[sl][c * 3 + 2], x2, acc);
-                    }
-                    sgh[tid + sl * kCellThreads] = fmaxf(acc, 0.0f);
+                for (int ks = 0; ks < kGhKS; ++ks) {
+                    const int kk = 4 * ks + q, c = kk / 3, k = kk - 3 * c, src = p - 1 + k;
+                    const float bv = (c < kHidden && p < C && src >= 0 && src < C) ? sh[c * C + src] : 0.0f;
+#pragma unroll
+                    for (int g = 0; g < kGhTiles; ++g)
+                        if (wv + NW * g < 4) acc[g] = mfma16(agh[g][ks], bv, acc[g]);
                 }
+#pragma unroll
+                for (int g = 0; g < kGhTiles; ++g)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int o = (wv + NW * g) * 16 + 4 * q + r;
+                        if (wv + NW * g < 4 && o < kGates && p < C) sgh[o * C + p] = fmaxf(acc[g][r], 0.0f);
+                    }
             }
-            __syncthreads();
+            DN_LDS_BARRIER();
             if (tid < kHidden * C) {   // chunk order r, i, n (gruunet2.py:234-240)   (17 C <= 85 < threads)
                 const float* gx = sd3 + (size_t)t * kGates * C;
                 const float r = sigmoidf_(gx[tid] + sgh[tid]);
@@ -376,47 +502,38 @@ __device__ __forceinline__ void cell_body(char* smem, const CellDev& cd, const f
                 sh[tid] = hn;
                 shi[t * kHidden * C + tid] = hn;
             }
-            __syncthreads();
+            if (t == 0) {
+                stgB.commit(level(5), wbuf[1], bbuf[1], tid);
+                stgB.issue(level(7), tid);
+            }
+            DN_LDS_BARRIER();
+            DN_CSTAMP(6 + t);
         }
         // ---- decoder, batched over the chunk (gruunet2.py:184-199); skips are d2, d1, d0 (the last level has no cat)
-        if (BF16) {
-            mconv_up_bf16<NW, false, 1>(cd.wb_up[0], cd.bt_up[0], shi, nullptr, su0, C, tt, wv, lane);
-            __syncthreads();
-            mconv_up_bf16<NW, true, 1>(cd.wb_up[1], cd.bt_up[1], su0, sd2, su1, 2 * C, tt, wv, lane);
-            __syncthreads();
-            mconv_up_bf16<NW, true, 2>(cd.wb_up[2], cd.bt_up[2], su1, sd1, su2, 4 * C, tt, wv, lane);
-        } else {
-            mconv_up<NW, false, 1>(cd.w_up[0], cd.bt_up[0], shi, nullptr, su0, C, tt, wv, lane);
-            __syncthreads();
-            mconv_up<NW, true, 1>(cd.w_up[1], cd.bt_up[1], su0, sd2, su1, 2 * C, tt, wv, lane);
-            __syncthreads();
-            mconv_up<NW, true, 2>(cd.w_up[2], cd.bt_up[2], su1, sd1, su2, 4 * C, tt, wv, lane);
-        }
-        __syncthreads();
-        // last level: one output channel; lane = (t, input position), weights through the scalar cache
-        {
-            const int l = 8 * C, items = tt * l;
-            cfloat_ptr wgt = (cfloat_ptr)cd.w_up[3];
-            for (int it = tid; it < items; it += kCellThreads) {
-                const int t = it / l, i = it - t * l;
-                float ev = cd.bt_up[3][2 * i], od = cd.bt_up[3][2 * i + 1];
-                const bool has_next = i + 1 < l;
-#pragma unroll 2
-                for (int c = 0; c < 2 * kHidden; ++c) {
-                    const float* src = c < kHidden ? su2 + ((size_t)t * kHidden + c) * l
-                                                   : sd0 + ((size_t)t * kHidden + (c - kHidden)) * l;
-                    const float x0 = src[i];
-                    const float x1 = has_next ? src[i + 1] : 0.0f;
-                    ev = fmaf(wgt[c * 3 + 1], x0, ev);
-                    od = fmaf(wgt[c * 3 + 2], x0, od);
-                    od = fmaf(wgt[c * 3 + 0], x1, od);
-                }
-                float* dst = out + (b * T + t0 + t) * F + 2 * i;
-                *reinterpret_cast<float2*>(dst) = make_float2(ev, od);
-            }
-        }
+        stgA.issue(level(6), tid);
+        if (BF16) mconv_up_bf16<NW, false, 1>(wbuf[0], bbuf[0], shi, nullptr, su0, C, tt, wv, lane);
+        else mconv_up<NW, false, 1>(wbuf[0], bbuf[0], shi, nullptr, su0, C, tt, wv, lane);
+        DN_LDS_BARRIER();
+        DN_CSTAMP(9);
+        if (BF16) mconv_up_bf16<NW, true, 1>(wbuf[1], bbuf[1], su0, sd2, su1, 2 * C, tt, wv, lane);
+        else mconv_up<NW, true, 1>(wbuf[1], bbuf[1], su0, sd2, su1, 2 * C, tt, wv, lane);
+        stgA.commit(level(6), wbuf[0], bbuf[0], tid);
+        DN_LDS_BARRIER();
+        DN_CSTAMP(10);
+        const bool more = t0 + kCellChunk < T;
+        if (more) stgA.issue(level(0), tid);
+        if (BF16) mconv_up_bf16<NW, true, 2>(wbuf[0], bbuf[0], su1, sd1, su2, 4 * C, tt, wv, lane);
+        else mconv_up<NW, true, 2>(wbuf[0], bbuf[0], su1, sd1, su2, 4 * C, tt, wv, lane);
+        stgB.commit(level(7), wbuf[1], bbuf[1], tid);
+        DN_LDS_BARRIER();
+        DN_CSTAMP(11);
+        // last level: one output channel (one row tile, 15 of its 16 rows idle), exact fp32 MFMA in both precisions; its rows are
+        // the model output.  The next chunk's first levels are on their way meanwhile.
+        if (more) stgB.issue(level(1), tid);
+        mconv_up<NW, true, 1, 1, true>(wbuf[1], bbuf[1], su2, sd0, out + (b * T + t0) * F, 8 * C, tt, wv, lane, (size_t)F);
     }
     __syncthreads();
+    DN_CSTAMP(12);
     // (hx_scale != 1: the server variant's `hx = hx * 0.9`, server.py:214)
     for (int i = tid; i < kHidden * C; i += kCellThreads) hx_out[b * kHidden * C + i] = sh[i] * hx_scale;
 }

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(64) void stft_general_kernel(DspDev d, const float*
 template <int NFFT>
 __global__ __launch_bounds__(kInvThreads) void server_rows_kernel(DspDev d, const float* __restrict__ logmel,
                                                                   const float* __restrict__ model_out,
-                                                                  const float2* __restrict__ spec_in, float2* __restrict__ spec_out) {
+                                                                  const float2* spec_in, float2* spec_out) {      // may alias (in-place): no __restrict__
     constexpr int kBins = Geo<NFFT>::kBins;
     constexpr int kRounds = (kBins + kInvThreads - 1) / kInvThreads;
     __shared__ float mm[kMaxMels];

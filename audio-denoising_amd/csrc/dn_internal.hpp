@@ -23,6 +23,16 @@ typedef const DN_CONST_AS float* cfloat_ptr;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #endif
 
+// Workgroup barrier that orders LDS traffic only: global loads issued before it stay in flight across it (a plain
+// __syncthreads() drains vmcnt first).  For phases that hand over LDS data while prefetches for later phases are pending.
+#ifndef DN_LDS_BARRIER
+#define DN_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
 constexpr int kHidden = 17;      // H
 constexpr int kGates = 51;       // 3H
 constexpr int kGauss = 6;        // G

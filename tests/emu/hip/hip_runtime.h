@@ -126,6 +126,7 @@ inline float shfl(float v, int src) {
 inline void __syncthreads() { dn_emu::ctx.block->wait(); }
 // workgroups run one after another and one thread per workgroup takes the ticket: a plain read-modify-write is enough
 inline unsigned int atomicAdd(unsigned int* p, unsigned int v) { unsigned int o = *p; *p = o + v; return o; }
+#define DN_LDS_BARRIER() __syncthreads()
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 #define __builtin_amdgcn_wave_barrier() dn_emu::ctx.wave->wait()
 #define __builtin_amdgcn_readfirstlane(x) (x)

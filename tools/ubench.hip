@@ -161,6 +161,44 @@ __global__ void xchg_kernel(float* out, uint64_t* cyc, float seed) {
     if (lane == 0) cyc[blockIdx.x * (blockDim.x / 64) + w] = t1 - t0;
 }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// MODE 0: one dependent accumulator chain of v_mfma_f32_16x16x4_f32; 1: four independent accumulators; 2: dependent chain whose A and B
+// operands come from ds_read_b32 issued just before (the conv tiles of the cell kernel); 3: v_mfma_f32_16x16x32_bf16 dependent chain
+template <int MODE>
+__global__ void mfma_kernel(float* out, uint64_t* cyc, float seed) {
+    __shared__ float lds[4096];
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < 4096; i += blockDim.x) lds[i] = seed * i;
+    __syncthreads();
+    f32x4 acc[4];
+    for (int i = 0; i < 4; ++i) acc[i] = f32x4{seed, seed, seed, seed};
+    float a = seed + lane, b = seed * lane;
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    bf16x8 ab, bb;
+    for (int i = 0; i < 8; ++i) { ab[i] = (__bf16)(seed + i); bb[i] = (__bf16)(seed * i); }
+    uint64_t t0, t1;
+    __builtin_amdgcn_sched_barrier(0);
+    STAMP(t0);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int it = 0; it < kIters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (MODE == 0) acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[0], 0, 0, 0);
+            if (MODE == 1) acc[r & 3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[r & 3], 0, 0, 0);
+            if (MODE == 2) {
+                const float aa = lds[(r * 64 + lane + it) & 4095], bb2 = lds[(r * 67 + 2 * lane + it) & 4095];
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(aa, bb2, acc[0], 0, 0, 0);
+            }
+            if (MODE == 3) acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ab, bb, acc[0], 0, 0, 0);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    STAMP(t1);
+    __builtin_amdgcn_sched_barrier(0);
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3];
+    if (lane == 0) cyc[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
+}
+
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
 template <typename K>
@@ -184,7 +222,7 @@ int main() {
     CK(hipMalloc(&out, 1 << 24));
     CK(hipMalloc(&cyc, 1 << 20));
     const double nv = (double)kIters * 32;
-    const int thr[] = {64, 256, 512, 768, 1024};
+    const int thr[] = {64, 256, 512};
     for (int t : thr) {
         run("v_pk_fma_f32 indep (per instr)", valu_kernel<0>, 256, t, nv, out, cyc);
         run("v_pk_add_f32 indep", valu_kernel<1>, 256, t, nv, out, cyc);
@@ -200,6 +238,12 @@ int main() {
     run("v_pk_fma_f32 dependent chain (per instr)", chain_kernel<0>, 256, 64, nv, out, cyc);
     run("v_fma_f32 dependent chain", chain_kernel<1>, 256, 64, nv, out, cyc);
     run("v_pk_fma_f32 dependent chain 2w/SIMD", chain_kernel<0>, 256, 512, nv, out, cyc);
+    for (int t : {64, 256}) {
+        run("mfma f32 16x16x4 dependent chain (per mfma)", mfma_kernel<0>, 256, t, (double)kIters * 16, out, cyc);
+        run("mfma f32 16x16x4 four accumulators", mfma_kernel<1>, 256, t, (double)kIters * 16, out, cyc);
+        run("mfma f32 16x16x4 dependent + 2 ds_read_b32 each", mfma_kernel<2>, 256, t, (double)kIters * 16, out, cyc);
+        run("mfma bf16 16x16x32 dependent chain", mfma_kernel<3>, 256, t, (double)kIters * 16, out, cyc);
+    }
     const int thr2[] = {64, 192, 256, 384, 512};
     for (int t : thr2) {
         run("tile exchange b64 round trip (per round)", xchg_kernel<0>, 256, t, kIters, out, cyc);
