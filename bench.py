@@ -123,17 +123,20 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(budget_s=24.0):
-    """The reference's op sequence on the host CPU (oracle, kind 'port'): batch 256 on every core this process may use,
-    batch 256 on ONE thread, and batch 1 (how the app really runs) -- a bounded sample of the same synthetic workload."""
+def cpu_baseline(budget_s=26.0):
+    """The reference's op sequence on the host CPU (oracle, kind 'port') on a bounded sample of the same synthetic workload: batch 256
+    with every core this process may use, with 4 threads and with ONE thread (torch's intra-op pool does not always scale on the
+    small tensors of this path: on the 16-core share of a GPU box one thread beat sixteen), and batch 1 (how the app really
+    runs).  `value` is the best of the batch-256 runs, `cores` the threads it used; all three are reported."""
     from oracle import dsp_ref, model_ref, pipeline_ref
     p = pipeline_ref.PARAMS_S
     sd = model_ref.unflatten_weights(np.fromfile(os.path.join(REPO, "tests", "golden", "weights_dari_tult.bin"), dtype=np.float32))
     fb = dsp_ref.melscale_fbanks(p.n_stft, p.n_mels, p.sample_rate)
     affinity = len(os.sched_getaffinity(0))
     cores = int(os.environ.get("DN_CPU_THREADS", str(usable_cores())))  # every core this process may use (affinity, cgroup quota)
+    runs = [(f"{t}t", BATCH, t, 0.28) for t in sorted({cores, min(cores, 4), 1}, reverse=True)] + [("b1", 1, cores, 0.12)]
     res = {}
-    for tag, B, threads, share in (("all", BATCH, cores, 0.45), ("one", BATCH, 1, 0.40), ("b1", 1, cores, 0.15)):
+    for tag, B, threads, share in runs:
         torch.set_num_threads(threads)
         g = torch.Generator().manual_seed(1234)
         frames = 0.1 * torch.randn(B, p.n_fft, generator=g)
@@ -141,9 +144,8 @@ def cpu_baseline(budget_s=24.0):
         gen = torch.Generator().manual_seed(4321)
         with torch.no_grad():
             tw = time.perf_counter()
-            if tag != "one":
-                r = pipeline_ref.process_frame(sd, frames, hx, p, fb, generator=gen)     # warm-up
-                hx = r["hx"]
+            r = pipeline_ref.process_frame(sd, frames, hx, p, fb, generator=gen)     # warm-up
+            hx = r["hx"]
             print(f"[bench] cpu baseline {tag}: B={B}, {threads} threads, warm-up {time.perf_counter() - tw:.2f} s", file=sys.stderr, flush=True)
             n, t0 = 0, time.perf_counter()
             while True:
@@ -153,15 +155,16 @@ def cpu_baseline(budget_s=24.0):
                 el = time.perf_counter() - t0
                 if el >= budget_s * share or n >= 200:
                     break
-        res[tag] = (B * n / el, n, el)
+        res[tag] = (B * n / el, n, el, threads)
     torch.set_num_threads(cores)
-    v, n, el = res["all"]
-    return {"value": round(v, 1), "unit": "frames/s", "cores": cores, "kind": "port",
+    best = max((k for k in res if k != "b1"), key=lambda k: res[k][0])
+    v, n, el, th = res[best]
+    return {"value": round(v, 1), "unit": "frames/s", "cores": th, "kind": "port",
             "sample": f"{n} steps of batch {BATCH} ({el:.1f} s) of the same synthetic workload through oracle/pipeline_ref.process_frame "
-                      f"(torch-CPU stft/matmul/conv1d/lstsq(gels)/32-iter Griffin-Lim, {cores} threads)",
+                      f"(torch-CPU stft/matmul/conv1d/lstsq(gels)/32-iter Griffin-Lim, {th} thread(s): the fastest of the thread counts tried)",
             "host": {"sched_getaffinity": affinity, "os_cpu_count": os.cpu_count(), "usable_cores": usable_cores()},
-            "one_thread_value": round(res["one"][0], 1),
-            "one_thread_sample": f"{res['one'][1]} steps of batch {BATCH} ({res['one'][2]:.1f} s), torch.set_num_threads(1)",
+            "by_threads": {str(res[k][3]): round(res[k][0], 1) for k in res if k != "b1"},
+            "one_thread_value": round(res["1t"][0], 1), "all_cores_value": round(res[f"{cores}t"][0], 1), "all_cores": cores,
             "batch1_value": round(res["b1"][0], 1)}
 
 
