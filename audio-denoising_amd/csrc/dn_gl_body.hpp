@@ -51,7 +51,13 @@ __device__ __forceinline__ v2f rand_angle(uint64_t seed, uint64_t sid, int col, 
 //                   computes P8-P10 in place -- leaky_relu(x - diff, 0.2), expm1, clamp, the pinv(fb^T)
 //                   contraction and relu (app3.py:203-211) -- into LDS, so the linear magnitudes never
 //                   touch HBM and the separate inverse-mel launch disappears from the fused hop.
-template <int NFFT> constexpr int gl_smem() { return 8 * 3 * Geo<NFFT>::kTile + 4 * 2 * 2 * NFFT; }    // 30,208 B at 1024
+// n_fft 1536 ("lean"): the per-lane window constants (synthesis window / NC: one table; analysis window x 1/envelope: one per
+// column) and the radix-12 twiddles live in LDS tables instead of 70 registers per lane, read back where they are used.  With
+// them in registers the body needs ~330 live values; capped at the 256 that let a Griffin-Lim and a front workgroup share a CU
+// it spilled ~75 of them to scratch in every iteration (188 us per batch-256 hop, round 1).
+template <int NFFT> constexpr bool gl_lean() { return NFFT == 1536; }
+template <int NFFT> constexpr int gl_tables() { return gl_lean<NFFT>() ? 8 * (4 * Geo<NFFT>::kNC + Geo<NFFT>::Fft::kPdTable) : 0; }
+template <int NFFT> constexpr int gl_smem() { return 8 * 3 * Geo<NFFT>::kTile + 4 * 2 * 2 * NFFT + gl_tables<NFFT>(); }    // 30,208 B at 1024, 77,824 B at 1536
 
 // One workgroup (192 threads = 3 wavefronts = 3 columns) runs all iterations for stream `b`.  `smem`: gl_smem<NFFT>() bytes.
 // STREAM = true: instead of storing the frame, fold it into the stream's overlap-add line (P12, app3.py:219-224):
@@ -68,6 +74,10 @@ __device__ __forceinline__ void gl_body(char* smem, const DspDev& d, const float
     v2f (*tile)[kFftTile] = reinterpret_cast<v2f (*)[kFftTile]>(smem);
     // [ping-pong][0: centre column, 1: halves of columns 0 and 2][n]
     float (*ybuf)[2][kNR] = reinterpret_cast<float (*)[2][kNR]>(smem + 8 * 3 * kFftTile);
+    constexpr bool kLean = gl_lean<NFFT>();
+    v2f* wsyn_t = reinterpret_cast<v2f*>(smem + 8 * 3 * kFftTile + 4 * 2 * 2 * kNR);        // [NC]       lean only
+    v2f* cw_t = wsyn_t + kNC;                                                                // [3][NC]
+    v2f* pd_t = kLean ? cw_t + 3 * kNC : nullptr;                                            // [11][64]
 
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -115,27 +125,35 @@ __device__ __forceinline__ void gl_body(char* smem, const DspDev& d, const float
     }
 
     typename G::Fft::Tw tw;
-    G::Fft::load(tw, reinterpret_cast<const v2f*>(d.twc), lane);
+    G::Fft::template load<!kLean>(tw, reinterpret_cast<const v2f*>(d.twc), lane);
+    if (kLean && w == 1) G::Fft::fill_pd(pd_t, reinterpret_cast<const v2f*>(d.twc), lane);
 
     // lane constants: bin twiddles of the owned pairs, synthesis window / NC, analysis window * 1/envelope
     // and the source sample indices of this column in the rebuilt signal s[0..n_fft)  (H = hop = n_fft/2):
     //   column 0: n < H -> s[H-n] (reflection), else s[n-H]
     //   column 1: s[n]
     //   column 2: n < H -> s[n+H], else s[3H-2-n] (reflection)
-    v2f wkh[kNP], wsyn[kNV], cw[kNV];
+    v2f wkh[kNP], wsyn[kLean ? 1 : kNV], cw[kLean ? 1 : kNV];
 #pragma unroll
     for (int t = 0; t < kNP; ++t) wkh[t] = cscale(reinterpret_cast<const v2f*>(d.twr)[lane + 64 * t], 0.5f);
 #pragma unroll
     for (int t = 0; t < kNV; ++t) {
         const int m = lane + 64 * t;
         const v2f ww = reinterpret_cast<const v2f*>(d.window)[m];
-        wsyn[t] = cscale(ww, 1.0f / (float)kNC);
+        const v2f ws = cscale(ww, 1.0f / (float)kNC);
         const int n0 = 2 * m, n1 = n0 + 1;
         int i0, i1;
         if (w == 1) { i0 = n0; i1 = n1; }
         else if (w == 0) { i0 = n0 < kHop ? kHop - n0 : n0 - kHop; i1 = n1 < kHop ? kHop - n1 : n1 - kHop; }
         else { i0 = n0 < kHop ? n0 + kHop : 3 * kHop - 2 - n0; i1 = n1 < kHop ? n1 + kHop : 3 * kHop - 2 - n1; }
-        cw[t] = mk2(ww[0] * d.inv_env[i0], ww[1] * d.inv_env[i1]);
+        const v2f cc = mk2(ww[0] * d.inv_env[i0], ww[1] * d.inv_env[i1]);
+        if (kLean) {
+            if (w == 0) wsyn_t[m] = ws;           // the same for every column: one table
+            cw_t[w * kNC + m] = cc;
+        } else {
+            wsyn[t] = ws;
+            cw[t] = cc;
+        }
     }
 
     // per-lane state: the NP bin pairs (k, NC-k), k = lane + 64 t, plus bin NC/2 (meaningful in lane 0)
@@ -170,7 +188,7 @@ __device__ __forceinline__ void gl_body(char* smem, const DspDev& d, const float
         x = a * (inv * m);
     };
 
-    if (FROM_MEL) __syncthreads();        // the prologue scratch becomes the overlap-add lines
+    if (FROM_MEL || kLean) __syncthreads();   // the prologue scratch becomes the overlap-add lines; the shared lean tables are complete
 
     // The iteration loop is instantiated once per column (W is a compile-time constant inside): the overlap-add
     // stores and every other column-dependent choice become straight-line code instead of per-value predicates.
@@ -188,7 +206,7 @@ __device__ __forceinline__ void gl_body(char* smem, const DspDev& d, const float
         DN_STAMP(0);
         irfft_merge_pairs<kNV>(xlo, xhi, xmid, wkh, lane, v);
         DN_STAMP(1);
-        G::Fft::template run<true>(v, tw, mytile, lane);
+        G::Fft::template run<true>(v, tw, mytile, lane, pd_t);
         DN_STAMP(2);
         float* y1 = ybuf[it & 1][0];
         float* yo = ybuf[it & 1][1];
@@ -198,7 +216,8 @@ __device__ __forceinline__ void gl_body(char* smem, const DspDev& d, const float
             float* ydst = W == 1 ? y1 : (W == 0 ? yo - kHop : yo + kHop);
             constexpr int t_lo = W == 0 ? kNP : 0, t_hi = W == 2 ? kNP : kNV;
 #pragma unroll
-            for (int t = t_lo; t < t_hi; ++t) *reinterpret_cast<v2f*>(ydst + 2 * (lane + 64 * t)) = v[t] * wsyn[t];
+            for (int t = t_lo; t < t_hi; ++t)
+                *reinterpret_cast<v2f*>(ydst + 2 * (lane + 64 * t)) = v[t] * (kLean ? wsyn_t[lane + 64 * t] : wsyn[kLean ? 0 : t]);
         }
         DN_STAMP(3);
         __syncthreads();
@@ -248,10 +267,10 @@ __device__ __forceinline__ void gl_body(char* smem, const DspDev& d, const float
             if (W == 1) { i0 = n0; i1 = n0 + 1; }
             else if (W == 0) { if (t < kNP) { i0 = kHop - n0; i1 = i0 - 1; } else { i0 = n0 - kHop; i1 = i0 + 1; } }
             else { if (t < kNP) { i0 = n0 + kHop; i1 = i0 + 1; } else { i0 = 3 * kHop - 2 - n0; i1 = i0 - 1; } }
-            v[t] = mk2(y1[i0] + yo[i0], y1[i1] + yo[i1]) * cw[t];
+            v[t] = mk2(y1[i0] + yo[i0], y1[i1] + yo[i1]) * (kLean ? cw_t[W * kNC + lane + 64 * t] : cw[kLean ? 0 : t]);
         }
         DN_STAMP(5);
-        G::Fft::template run<false>(v, tw, mytile, lane);
+        G::Fft::template run<false>(v, tw, mytile, lane, pd_t);
         DN_STAMP(6);
         rfft_split_pairs<kNV>(v, wkh, lane, rlo, rhi, rmid);
         DN_STAMP(7);

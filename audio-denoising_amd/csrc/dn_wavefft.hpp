@@ -98,6 +98,9 @@ template <> struct WaveFft<512> {
     static constexpr int kTile = 576;        // complex entries of the exchange tile (512 + padding)
     struct Tw { v2f p1[7], p2[7]; };         // exp(-2 pi i (j&7) t/64), exp(-2 pi i j t/512), t = 1..7
     // twc[k] = exp(-2 pi i k / NC), k = 0..NC-1 (device global table, built on the host in double)
+    static constexpr int kPdTable = 0;
+    static __device__ __forceinline__ void fill_pd(v2f*, const v2f* __restrict__, int) {}
+    template <bool WITH_PD = true>
     static __device__ __forceinline__ void load(Tw& tw, const v2f* __restrict__ twc, int lane) {
 #pragma unroll
         for (int t = 1; t < 8; ++t) {
@@ -110,7 +113,7 @@ template <> struct WaveFft<512> {
     static __device__ __forceinline__ int pad1(int c) { return c + ((c >> 6) << 3); }
 
     template <bool INV>
-    static __device__ __forceinline__ void run(v2f (&v)[8], const Tw& tw, v2f* tile, int lane) {
+    static __device__ __forceinline__ void run(v2f (&v)[8], const Tw& tw, v2f* tile, int lane, const v2f* = nullptr) {
         dft8<INV>(v);                                         // pass 0 (Ns = 1)
         wave_sync();                                          // previous readers of the tile are done
 #pragma unroll
@@ -140,14 +143,25 @@ template <> struct WaveFft<768> {
     static constexpr int kNV = 12;
     static constexpr int kTile = 960;        // 768 + padding of the widest map
     struct Tw { v2f pb[3], pc[3], pd[11]; }; // passes B (Ns=4), C (Ns=16): r = 1..3;  pass D (Ns=64, R=12): r = 1..11
+    // WITH_PD = false leaves the eleven radix-12 twiddles out of the registers: the caller keeps them in an LDS table instead
+    // (`pd_lds[(r-1)*64 + lane]`, fill_pd) and passes it to run() -- the Griffin-Lim body at n_fft 1536, whose 330 live values
+    // do not fit the 256 registers that let two workgroups share a CU.
+    template <bool WITH_PD = true>
     static __device__ __forceinline__ void load(Tw& tw, const v2f* __restrict__ twc, int lane) {
 #pragma unroll
         for (int r = 1; r < 4; ++r) {
             tw.pb[r - 1] = twc[(lane & 3) * r * 48];          // exp(-2 pi i (j%4) r / 16)
             tw.pc[r - 1] = twc[(lane & 15) * r * 12];         // exp(-2 pi i (j%16) r / 64)
         }
+        if (WITH_PD) {
 #pragma unroll
-        for (int r = 1; r < 12; ++r) tw.pd[r - 1] = twc[lane * r];             // exp(-2 pi i j r / 768)
+            for (int r = 1; r < 12; ++r) tw.pd[r - 1] = twc[lane * r];         // exp(-2 pi i j r / 768)
+        }
+    }
+    static constexpr int kPdTable = 11 * 64;                  // complex entries of the LDS twiddle table
+    static __device__ __forceinline__ void fill_pd(v2f* pd_lds, const v2f* __restrict__ twc, int lane) {
+#pragma unroll
+        for (int r = 1; r < 12; ++r) pd_lds[(r - 1) * 64 + lane] = twc[lane * r];
     }
     static __device__ __forceinline__ int padA(int c) { return c + (c >> 4); }
     static __device__ __forceinline__ int padB(int c) { return c + ((c >> 4) << 2); }
@@ -167,7 +181,7 @@ template <> struct WaveFft<768> {
     }
 
     template <bool INV>
-    static __device__ __forceinline__ void run(v2f (&v)[12], const Tw& tw, v2f* tile, int lane) {
+    static __device__ __forceinline__ void run(v2f (&v)[12], const Tw& tw, v2f* tile, int lane, const v2f* pd_lds = nullptr) {
         // pass A (R=4, Ns=1): out[4 j + r], j = lane + 64 g
         pass4<INV, false>(v, tw.pb);
         wave_sync();
@@ -199,8 +213,13 @@ template <> struct WaveFft<768> {
 #pragma unroll
         for (int t = 0; t < 12; ++t) v[t] = tile[lane + 64 * t];
         // pass D (R=12, Ns=64): one butterfly per lane, output index lane + 64 r stays in registers
+        if (pd_lds != nullptr) {
 #pragma unroll
-        for (int r = 1; r < 12; ++r) v[r] = twmul<INV>(v[r], tw.pd[r - 1]);
+            for (int r = 1; r < 12; ++r) v[r] = twmul<INV>(v[r], pd_lds[(r - 1) * 64 + lane]);
+        } else {
+#pragma unroll
+            for (int r = 1; r < 12; ++r) v[r] = twmul<INV>(v[r], tw.pd[r - 1]);
+        }
         dft12<INV>(v);
     }
 };
