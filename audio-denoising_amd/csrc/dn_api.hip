@@ -1,6 +1,7 @@
 // dn_api.hip -- the C ABI of include/dn_denoise.h: handle construction (host-side packing of
 // the reference's tensors into kernel-friendly layouts) and launch wrappers.  No kernel code here.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <atomic>
@@ -139,6 +140,8 @@ struct dn_pipe {
     dn::PipeCtl* ctl = nullptr;               // device-resident hop counter / pending flag (what makes a captured launch replayable)
     float* scratch[2] = {nullptr, nullptr};   // per slot: mel [B][3][M], residual [B][3][M], peak [B], meta [B][8], lin [B][3][K]
     float2* scratch_init[2] = {nullptr, nullptr};   // per slot: the frame's initial phases (allocated on first parity-mode use)
+    float2* gl_state[2] = {nullptr, nullptr};       // per slot: a Griffin-Lim chain parked by the head start ([B][3][2 NV + 2][64] complex)
+    int gl_split = 0;                               // iterations of head start (0 = none)
     BiasSet* bs = nullptr;
     float* last_out = nullptr;                // frame mode: where the pending hop's frames go
     // streaming mode: per-stream state owned by the pipe
@@ -450,7 +453,7 @@ int dn_dsp_create(const dn_dsp_cfg* cfg, const float* fb_in, const float* pinv_i
     size_t o_win = d->arena.add(d->window.data(), N * 4), o_env = d->arena.add(inv_env.data(), N * 4);
     size_t o_ms = 0, o_ml = 0, o_mw = 0, o_pinv = 0;
     int maxlen = 0;
-    const int pstride = ((K + 191) / 192) * 192;      // the contraction kernels stream rows in 192-bin rounds
+    const int pstride = ((K + 767) / 768) * 768;      // the contraction kernels stream rows in rounds of 192 or 256 bins (zero padded: tail loads stay in bounds)
     if (M > 0) {
         d->fb.resize((size_t)K * M);
         if (fb_in) memcpy(d->fb.data(), fb_in, d->fb.size() * 4);
@@ -735,6 +738,14 @@ int dn_pipe_create(const dn_model* m, const dn_dsp* d, int32_t B, uint32_t flags
     if (e == hipSuccess) e = hipMemset(p->ctl, 0, 256);
     for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipMalloc(reinterpret_cast<void**>(&p->scratch[i]), slot);
     if (e != hipSuccess) { dn_pipe_destroy(p); return fail(DN_ERR_HIP, std::string("dn_pipe_create: ") + hipGetErrorString(e)); }
+    {
+        // Griffin-Lim head start: with at most one stream per CU (MI355X: 256 CUs) a front workgroup has slack at the end of a launch that
+        // the pending hop's chain does not -- measured best at 2-4 iterations for n_fft 1024 (65.0 -> 62 us per batch-256 hop) and 6-7 for
+        // n_fft 1536 (131 -> 111 us); with more streams than CUs every workgroup is busy throughout and it only adds traffic.
+        const char* hs = getenv("DN_GL_HEAD_START");          // (experiments: tools/head_start_sweep.sh)
+        const int it = hs ? atoi(hs) : (B <= 256 ? (d->cfg.n_fft == 1536 ? 6 : 3) : 0);
+        if (it > 0) { rc = dn_pipe_set_head_start(p, it); if (rc != DN_OK) { dn_pipe_destroy(p); return rc; } }
+    }
     *out = p;
     return DN_OK;
 }
@@ -744,6 +755,7 @@ void dn_pipe_destroy(dn_pipe* p) {
     for (int i = 0; i < 2; ++i) {
         if (p->scratch[i]) (void)hipFree(p->scratch[i]);
         if (p->scratch_init[i]) (void)hipFree(p->scratch_init[i]);
+        if (p->gl_state[i]) (void)hipFree(p->gl_state[i]);
     }
     if (p->ctl) (void)hipFree(p->ctl);
     if (p->ring) (void)hipFree(p->ring);
@@ -752,6 +764,17 @@ void dn_pipe_destroy(dn_pipe* p) {
     model_release(p->m);
     dsp_release(p->d);
     delete p;
+}
+
+int dn_pipe_set_head_start(dn_pipe* p, int32_t iterations) {
+    if (!p || iterations < 0) return fail(DN_ERR_INVALID, "dn_pipe_set_head_start: bad argument");
+    if (iterations > 0 && !p->gl_state[0]) {
+        const size_t nv = (size_t)p->d->cfg.n_fft / 128;       // complex values per lane
+        const size_t bytes = (size_t)p->B * 3 * (2 * nv + 2) * 64 * sizeof(float2);
+        for (int i = 0; i < 2; ++i) DN_HIP(hipMalloc(reinterpret_cast<void**>(&p->gl_state[i]), bytes));
+    }
+    p->gl_split = iterations;
+    return DN_OK;
 }
 
 int dn_pipe_set_model(dn_pipe* p, const dn_model* m) {
@@ -835,7 +858,8 @@ static int fill_hop_args(dn_pipe* p, dn::HopArgs& a, const float* init_angles, u
         if (rc != DN_OK) return rc;
     }
     a.ctl = p->ctl;
-    for (int i = 0; i < 2; ++i) { a.slot[i] = p->scratch[i]; a.slot_init[i] = p->scratch_init[i]; }
+    for (int i = 0; i < 2; ++i) { a.slot[i] = p->scratch[i]; a.slot_init[i] = p->scratch_init[i]; a.gl_state[i] = p->gl_state[i]; }
+    a.gl_split = p->gl_split;
     a.init_in = init_angles; a.seed = seed; a.sid0 = stream_id0;
     a.n_iter = n_iter; a.mom = momentum / (1.0f + momentum);
     a.B = p->B; a.C = p->C; a.back_B = p->B;

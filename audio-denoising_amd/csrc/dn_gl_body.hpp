@@ -67,7 +67,12 @@ __device__ __forceinline__ void gl_body(char* smem, const DspDev& d, const float
                                         const float* __restrict__ diff, const v2f* __restrict__ init, uint64_t seed,
                                         uint64_t sid0, const float* __restrict__ scale, float* __restrict__ wave,
                                         int n_iter, float mom, size_t b, int tid, float* ola = nullptr,
-                                        void* hop_out = nullptr, int out_s16 = 0) {
+                                        void* hop_out = nullptr, int out_s16 = 0, int it_begin = 0, int it_stop = -1,
+                                        v2f* state = nullptr) {
+    // it_begin / it_stop / state: the chain can be cut at the top of an iteration.  A call with it_stop = s >= 0 runs iterations
+    // [it_begin, s) and leaves X = angles * magnitude and the previous rebuilt spectrum of every lane in `state`
+    // ([stream][column][2 NV + 2][64] complex, one coalesced row per register); a call with it_begin = s > 0 picks them up and runs on.
+    // Everything else an iteration needs is rebuilt from those two, so the continuation is bit-identical to the uncut chain.
     using G = Geo<NFFT>;
     constexpr int kNR = G::kNR, kNC = G::kNC, kHop = G::kHop, kBins = G::kBins, kNV = G::kNV, kNP = G::kNP, kFftTile = G::kTile;
     constexpr int kBinPad = (kBins + 7) & ~7;                  // row stride of the LDS magnitude scratch
@@ -166,13 +171,15 @@ __device__ __forceinline__ void gl_body(char* smem, const DspDev& d, const float
             const int k = lane + 64 * t, kh = kNC - k;
             mlo[t] = FROM_MEL ? lmag[w * kBinPad + k] : (mag != nullptr ? mag[row + k] : 1.0f);
             mhi[t] = FROM_MEL ? lmag[w * kBinPad + kh] : (mag != nullptr ? mag[row + kh] : 1.0f);
-            alo[t] = init != nullptr ? init[row + k] : rand_angle(seed, sid0 + b, w, k);
-            ahi[t] = init != nullptr ? init[row + kh] : rand_angle(seed, sid0 + b, w, kh);
+            if (it_begin == 0) {
+                alo[t] = init != nullptr ? init[row + k] : rand_angle(seed, sid0 + b, w, k);
+                ahi[t] = init != nullptr ? init[row + kh] : rand_angle(seed, sid0 + b, w, kh);
+            }
             plo[t] = mk2(0.0f, 0.0f);
             phi[t] = mk2(0.0f, 0.0f);
         }
         mmid = FROM_MEL ? lmag[w * kBinPad + kNC / 2] : (mag != nullptr ? mag[row + kNC / 2] : 1.0f);
-        amid = init != nullptr ? init[row + kNC / 2] : rand_angle(seed, sid0 + b, w, kNC / 2);
+        if (it_begin == 0) amid = init != nullptr ? init[row + kNC / 2] : rand_angle(seed, sid0 + b, w, kNC / 2);
         pmid = mk2(0.0f, 0.0f);
     }
 
@@ -192,16 +199,37 @@ __device__ __forceinline__ void gl_body(char* smem, const DspDev& d, const float
 
     // The iteration loop is instantiated once per column (W is a compile-time constant inside): the overlap-add
     // stores and every other column-dependent choice become straight-line code instead of per-value predicates.
+    v2f* mystate = state != nullptr ? state + ((b * 3 + w) * (2 * kNV + 2)) * 64 + lane : nullptr;
     auto iterate = [&](auto wc) {
     constexpr int W = decltype(wc)::value;
     v2f v[kNV], xlo[kNP], xhi[kNP], xmid, rlo[kNP], rhi[kNP], rmid;
+    if (it_begin > 0) {
 #pragma unroll
-    for (int t = 0; t < kNP; ++t) {
-        xlo[t] = alo[t] * mlo[t];
-        xhi[t] = ahi[t] * mhi[t];
+        for (int t = 0; t < kNP; ++t) {
+            xlo[t] = mystate[64 * t]; xhi[t] = mystate[64 * (kNP + t)];
+            plo[t] = mystate[64 * (kNV + 1 + t)]; phi[t] = mystate[64 * (kNV + 1 + kNP + t)];
+        }
+        xmid = mystate[64 * kNV];
+        pmid = mystate[64 * (2 * kNV + 1)];
+    } else {
+#pragma unroll
+        for (int t = 0; t < kNP; ++t) {
+            xlo[t] = alo[t] * mlo[t];
+            xhi[t] = ahi[t] * mhi[t];
+        }
+        xmid = amid * mmid;
     }
-    xmid = amid * mmid;
-    for (int it = 0;; ++it) {
+    for (int it = it_begin;; ++it) {
+        if (it == it_stop) {          // hand the chain over (uniform)
+#pragma unroll
+            for (int t = 0; t < kNP; ++t) {
+                mystate[64 * t] = xlo[t]; mystate[64 * (kNP + t)] = xhi[t];
+                mystate[64 * (kNV + 1 + t)] = plo[t]; mystate[64 * (kNV + 1 + kNP + t)] = phi[t];
+            }
+            mystate[64 * kNV] = xmid;
+            mystate[64 * (2 * kNV + 1)] = pmid;
+            break;
+        }
         // ---- istft of X = angles * magnitude: Hermitian merge, inverse FFT, synthesis window, overlap-add lines
         DN_STAMP(0);
         irfft_merge_pairs<kNV>(xlo, xhi, xmid, wkh, lane, v);

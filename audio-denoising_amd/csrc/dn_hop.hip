@@ -24,21 +24,25 @@
 
 namespace dn {
 
-constexpr int kHopThreads = 192;
+constexpr int kHopThreads = 192;          // the Griffin-Lim chain: one wavefront per STFT column
+constexpr int kHopPipeThreads = 256;      // workgroup size of the fused launches: a fourth wavefront for the front half
+#ifndef DN_GL_PRIO
+#define DN_GL_PRIO 3
+#endif
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 template <int NFFT> constexpr int hop_smem() { return cmax(cmax(kCellSmem, gl_smem<NFFT>()), cmax(stft_smem<NFFT>(), kInvSmem)); }
 static_assert(kHopThreads == kGlThreads && kHopThreads == kStftThreads && kHopThreads == kInvThreads, "one block size for all bodies");
 
 // ring <- concat(ring[hop:], hop_in): every thread holds its float4s before anything is overwritten   (app3.py:174,226)
-template <int NFFT>
+template <int NFFT, int THREADS = kHopThreads>
 __device__ __forceinline__ void ring_shift(float* ring, const void* hop_in, int in_s16, size_t b, int tid) {
     constexpr int kNR = NFFT, kLine4 = kNR / 4, kHop4 = kNR / 8;
-    static_assert(kLine4 <= 2 * kHopThreads, "two float4 per thread cover the line");
+    static_assert(kLine4 <= 2 * THREADS, "two float4 per thread cover the line");
     float4* r4 = reinterpret_cast<float4*>(ring + b * kNR);
     float4 v[2];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-        const int i4 = tid + kHopThreads * r;
+        const int i4 = tid + THREADS * r;
         v[r] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i4 < kLine4 - kHop4) v[r] = r4[i4 + kHop4];
         else if (i4 < kLine4) {
@@ -54,7 +58,7 @@ __device__ __forceinline__ void ring_shift(float* ring, const void* hop_in, int 
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-        const int i4 = tid + kHopThreads * r;
+        const int i4 = tid + THREADS * r;
         if (i4 < kLine4) r4[i4] = v[r];
     }
     __syncthreads();
@@ -71,8 +75,12 @@ struct SlotLayout {
 // n_fft 1536: the Griffin-Lim body would take 330 registers and shut the front workgroup out of the CU; capping the
 // kernel at two waves per SIMD (256 registers, ~80 values spilled to scratch) keeps both halves resident (+30 % at 1024
 // streams).  n_fft 1024 fits in 229 registers without a cap (capping it costs 8 %).
+// The pipelined launch uses workgroups of FOUR wavefronts.  A Griffin-Lim workgroup needs three (one per column): its fourth exits at
+// once.  A front workgroup uses all four: its waves share SIMDs with the Griffin-Lim waves of the same CU (six or seven waves on four
+// SIMDs) and its phases end at workgroup barriers, so the front half -- not the Griffin-Lim chain -- was what ended a batch-256 launch
+// (measured: two iterations moved INTO the front workgroup cost 4.8 us); a fourth wave shortens every conv phase by a quarter.
 template <int NFFT, bool STREAM, bool BF16>
-__global__ __launch_bounds__(kHopThreads, NFFT == 1536 ? 2 : 1) void hop_kernel(DspDev d, CellDev cd, HopArgs a) {
+__global__ __launch_bounds__(kHopPipeThreads, NFFT == 1536 ? 2 : 1) void hop_kernel(DspDev d, CellDev cd, HopArgs a) {
     constexpr int kNR = NFFT, kBins = Geo<NFFT>::kBins;
     __shared__ __attribute__((aligned(16))) char smem[hop_smem<NFFT>()];
     const int tid = threadIdx.x;
@@ -83,25 +91,29 @@ __global__ __launch_bounds__(kHopThreads, NFFT == 1536 ? 2 : 1) void hop_kernel(
     const bool priming = STREAM && pushes < (unsigned long long)a.prime;
     if ((int)blockIdx.x < a.back_B) {
         const size_t b = blockIdx.x;
+        if (tid >= kHopThreads) return;         // (before any barrier: a terminated wave no longer counts at s_barrier)
         if (pending) {
             // the Griffin-Lim chain is the critical path of the launch: let its waves win issue arbitration against the
             // front-half waves they share SIMDs with
-            __builtin_amdgcn_s_setprio(3);
+            __builtin_amdgcn_s_setprio(DN_GL_PRIO);
             const int s = (int)((frames - 1) & 1);
             const float* slot = a.slot[s];
             const uint32_t* meta = reinterpret_cast<const uint32_t*>(slot + sl.meta) + 8 * b;
             const v2f* init = meta[0] ? reinterpret_cast<const v2f*>(a.slot_init[s]) : nullptr;
             const uint64_t seed = (uint64_t)meta[1] | ((uint64_t)meta[2] << 32);
             const uint64_t sid0 = (uint64_t)meta[3] | ((uint64_t)meta[4] << 32);
+            const int it0 = (int)meta[5];          // iterations the frame's front workgroup already ran (head start)
+            v2f* st = reinterpret_cast<v2f*>(a.gl_state[s]);
             if (!STREAM)
-                gl_body<NFFT, false, false>(smem, d, slot + sl.lin, nullptr, init, seed, sid0, slot + sl.peak, a.gl_out, a.n_iter, a.mom, b, tid);
+                gl_body<NFFT, false, false>(smem, d, slot + sl.lin, nullptr, init, seed, sid0, slot + sl.peak, a.gl_out, a.n_iter, a.mom, b, tid,
+                                            nullptr, nullptr, 0, it0, -1, st);
             else
                 gl_body<NFFT, false, true>(smem, d, slot + sl.lin, nullptr, init, seed, sid0, slot + sl.peak, nullptr, a.n_iter, a.mom, b, tid,
-                                           a.ola, a.hop_out, a.out_s16);
+                                           a.ola, a.hop_out, a.out_s16, it0, -1, st);
             __builtin_amdgcn_s_setprio(0);
         } else if (STREAM) {
             // nothing to emit yet: the reference's ola[:hop] is still zero (app3.py:133,219)
-            for (int n = tid; n < kNR / 2; n += kHopThreads) {
+            for (int n = tid; n < kNR / 2; n += kHopThreads) {      // (three waves are left)
                 if (a.out_s16) static_cast<short*>(a.hop_out)[b * (kNR / 2) + n] = 0;
                 else static_cast<float*>(a.hop_out)[b * (kNR / 2) + n] = 0.0f;
             }
@@ -110,18 +122,19 @@ __global__ __launch_bounds__(kHopThreads, NFFT == 1536 ? 2 : 1) void hop_kernel(
         const size_t b = blockIdx.x - a.back_B;
         const float* frames_in = a.frames;
         if (STREAM) {
-            ring_shift<NFFT>(a.ring, a.hop_in, a.in_s16, b, tid);
+            ring_shift<NFFT, kHopPipeThreads>(a.ring, a.hop_in, a.in_s16, b, tid);
             frames_in = a.ring;
         }
         if (!priming) {
             const int s = (int)(frames & 1);
             float* slot = a.slot[s];
-            stft_body<NFFT, false, true>(smem, d, frames_in, nullptr, slot, slot + sl.peak, DN_PEAK_NORMALIZE | DN_PRE_WINDOW, b, tid);   // P1-P6
+            stft_body<NFFT, false, true, kHopPipeThreads>(smem, d, frames_in, nullptr, slot, slot + sl.peak, DN_PEAK_NORMALIZE | DN_PRE_WINDOW, b, tid);   // P1-P6
             __syncthreads();
-            cell_body<kHopThreads / 64, BF16>(smem, cd, slot, a.hx, slot + sl.diff, a.hx, 3, a.C, b, tid);                                // P7
+            cell_body<kHopPipeThreads / 64, BF16>(smem, cd, slot, a.hx, slot + sl.diff, a.hx, 3, a.C, b, tid);                            // P7
             __syncthreads();
-            invmel_body<NFFT, true>(smem, d, slot, slot + sl.diff, slot + sl.lin, 3 * a.B, b * 3, tid);                                   // P8-P10
+            invmel_body<NFFT, true, kHopPipeThreads>(smem, d, slot, slot + sl.diff, slot + sl.lin, 3 * a.B, b * 3, tid);                  // P8-P10
             // what this frame's Griffin-Lim (next launch) needs besides the magnitudes: its seed, its stream ids and, in parity mode, its phases
+            const int split = min(a.gl_split, a.n_iter);
             if (tid == 0) {
                 uint32_t* meta = reinterpret_cast<uint32_t*>(slot + sl.meta) + 8 * b;
                 const uint64_t seed = a.seed + frames;
@@ -130,11 +143,22 @@ __global__ __launch_bounds__(kHopThreads, NFFT == 1536 ? 2 : 1) void hop_kernel(
                 meta[2] = (uint32_t)(seed >> 32);
                 meta[3] = (uint32_t)a.sid0;
                 meta[4] = (uint32_t)(a.sid0 >> 32);
+                meta[5] = (uint32_t)split;
             }
             if (a.init_in != nullptr) {
                 const float2* src = reinterpret_cast<const float2*>(a.init_in) + b * 3 * kBins;
                 float2* dst = a.slot_init[s] + b * 3 * kBins;
-                for (int i = tid; i < 3 * kBins; i += kHopThreads) dst[i] = src[i];
+                for (int i = tid; i < 3 * kBins; i += kHopPipeThreads) dst[i] = src[i];
+            }
+            if (split > 0) {
+                // head start: this workgroup would idle for the rest of the launch (the pending hop's chain is ~1.5x longer than P1-P10)
+                __syncthreads();                       // the magnitudes are in the slot
+                if (tid >= kHopThreads) return;        // the chain is three waves wide
+                __builtin_amdgcn_s_setprio(1);         // below the pending hop's chain (3): that one ends the launch
+                gl_body<NFFT, false, false>(smem, d, slot + sl.lin, nullptr, reinterpret_cast<const v2f*>(a.init_in), a.seed + frames, a.sid0,
+                                            nullptr, nullptr, a.n_iter, a.mom, b, tid, nullptr, nullptr, 0, 0, split,
+                                            reinterpret_cast<v2f*>(a.gl_state[s]));
+                __builtin_amdgcn_s_setprio(0);
             }
         }
     }
@@ -161,7 +185,7 @@ __global__ __launch_bounds__(kHopThreads, NFFT == 1536 ? 2 : 1) void hop_kernel(
 
 template <int NFFT, bool STREAM>
 static void launch_hop_n(const DspDev& d, const CellDev& c, const HopArgs& a, bool bf16, hipStream_t st) {
-    const dim3 grid(a.back_B + a.front_B), block(kHopThreads);
+    const dim3 grid(a.back_B + a.front_B), block(kHopPipeThreads);
     if (bf16) hipLaunchKernelGGL((hop_kernel<NFFT, STREAM, true>), grid, block, 0, st, d, c, a);
     else hipLaunchKernelGGL((hop_kernel<NFFT, STREAM, false>), grid, block, 0, st, d, c, a);
 }
@@ -184,21 +208,23 @@ void launch_ctl_set(PipeCtl* ctl, unsigned long long pushes, unsigned long long 
     hipLaunchKernelGGL(ctl_set_kernel, dim3(1), dim3(1), 0, st, ctl, pushes, frames, pending);
 }
 
-// ---- the unpipelined hop: P1-P12 of one stream in one workgroup, one launch per hop (zero added latency)
+// ---- the unpipelined hop: P1-P12 of one stream in one workgroup, one launch per hop (zero added latency).  Four wavefronts for the
+// front half (the conv phases split four ways), three for the Griffin-Lim chain behind it (the fourth exits).
 template <int NFFT, bool STREAM, bool BF16>
-__global__ __launch_bounds__(kHopThreads, NFFT == 1536 ? 2 : 1) void frame_kernel(DspDev d, CellDev cd, FrameArgs a) {
+__global__ __launch_bounds__(kHopPipeThreads, NFFT == 1536 ? 2 : 1) void frame_kernel(DspDev d, CellDev cd, FrameArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[hop_smem<NFFT>()];
     const int tid = threadIdx.x;
     const size_t b = blockIdx.x;
     const float* frames_in = a.frames;
     if (STREAM) {
-        ring_shift<NFFT>(a.ring, a.hop_in, 0, b, tid);
+        ring_shift<NFFT, kHopPipeThreads>(a.ring, a.hop_in, 0, b, tid);
         frames_in = a.ring;
     }
-    stft_body<NFFT, false, true>(smem, d, frames_in, nullptr, a.mel, a.peak, DN_PEAK_NORMALIZE | DN_PRE_WINDOW, b, tid);        // P1-P6
+    stft_body<NFFT, false, true, kHopPipeThreads>(smem, d, frames_in, nullptr, a.mel, a.peak, DN_PEAK_NORMALIZE | DN_PRE_WINDOW, b, tid);   // P1-P6
     __syncthreads();
-    cell_body<kHopThreads / 64, BF16>(smem, cd, a.mel, a.hx, a.diff, a.hx, 3, a.C, b, tid);                                     // P7
+    cell_body<kHopPipeThreads / 64, BF16>(smem, cd, a.mel, a.hx, a.diff, a.hx, 3, a.C, b, tid);                                          // P7
     __syncthreads();
+    if (tid >= kHopThreads) return;
     // P8-P12: the inverse-mel contraction is the Griffin-Lim prologue (the linear magnitudes stay in LDS)
     if (!STREAM)
         gl_body<NFFT, true, false>(smem, d, a.mel, a.diff, reinterpret_cast<const v2f*>(a.init), a.seed, a.sid0, a.peak, a.out, a.n_iter, a.mom, b, tid);
@@ -209,8 +235,8 @@ __global__ __launch_bounds__(kHopThreads, NFFT == 1536 ? 2 : 1) void frame_kerne
 
 template <int NFFT, bool STREAM>
 static void launch_frame_n(const DspDev& d, const CellDev& c, const FrameArgs& a, int B, bool bf16, hipStream_t st) {
-    if (bf16) hipLaunchKernelGGL((frame_kernel<NFFT, STREAM, true>), dim3(B), dim3(kHopThreads), 0, st, d, c, a);
-    else hipLaunchKernelGGL((frame_kernel<NFFT, STREAM, false>), dim3(B), dim3(kHopThreads), 0, st, d, c, a);
+    if (bf16) hipLaunchKernelGGL((frame_kernel<NFFT, STREAM, true>), dim3(B), dim3(kHopPipeThreads), 0, st, d, c, a);
+    else hipLaunchKernelGGL((frame_kernel<NFFT, STREAM, false>), dim3(B), dim3(kHopPipeThreads), 0, st, d, c, a);
 }
 
 void launch_frame(const DspDev& d, const CellDev& c, const FrameArgs& a, int B, bool bf16, hipStream_t st) {

@@ -72,6 +72,9 @@ struct HopArgs {
     // back half: the pending hop's Griffin-Lim, read from slot (frames - 1) & 1
     float* gl_out;
     int n_iter; float mom;
+    // head start: the front workgroup, done with P1-P10 long before the launch ends, runs the first `gl_split` Griffin-Lim iterations of
+    // ITS frame and parks the chain in gl_state[slot]; the back workgroup of the next launch resumes there (0 = no head start)
+    int gl_split; float2* gl_state[2];
     int front_B, back_B, B, C;
     // streaming mode (pipe-owned per-stream state): the front half first shifts `hop_in` into `ring` and uses the ring
     // as its frame (app3.py:178,226); the back half folds its frame into `ola` and emits `hop_out` (app3.py:219-224)

@@ -12,14 +12,14 @@ constexpr int kMaxMels = 128;
 constexpr int kInvSmem = 4 * kInvRows * kMaxMels;
 
 // One workgroup (192 threads) handles rows r0 .. r0+2 (the three columns of one stream).  `smem`: kInvSmem bytes.
-template <int NFFT, bool RESIDUAL>
+template <int NFFT, bool RESIDUAL, int THREADS = kInvThreads>
 __device__ __forceinline__ void invmel_body(char* smem, const DspDev& d, const float* __restrict__ x,
                                             const float* __restrict__ diff, float* __restrict__ lin, int rows,
                                             size_t r0, int tid) {
     constexpr int kBins = Geo<NFFT>::kBins;
     float (*mm)[kMaxMels] = reinterpret_cast<float (*)[kMaxMels]>(smem);
     const int M = d.n_mels;
-    for (int i = tid; i < kInvRows * M; i += kInvThreads) {
+    for (int i = tid; i < kInvRows * M; i += THREADS) {
         const int r = i / M, m = i - r * M;
         float v = 0.0f;
         if (r0 + r < (size_t)rows) {
@@ -34,7 +34,7 @@ __device__ __forceinline__ void invmel_body(char* smem, const DspDev& d, const f
     }
     __syncthreads();
     // thread <-> bins tid, tid+192, ..: independent load streams (pinv_t rows are zero padded to a multiple of 192)
-    constexpr int kRounds = (kBins + kInvThreads - 1) / kInvThreads;
+    constexpr int kRounds = (kBins + THREADS - 1) / THREADS;
     float acc[kRounds][3];
 #pragma unroll
     for (int r = 0; r < kRounds; ++r) acc[r][0] = acc[r][1] = acc[r][2] = 0.0f;
@@ -45,13 +45,13 @@ __device__ __forceinline__ void invmel_body(char* smem, const DspDev& d, const f
         const float m0 = mm[0][m], m1 = mm[1][m], m2 = mm[2][m];
 #pragma unroll
         for (int r = 0; r < kRounds; ++r) {
-            const float pv = pm[kInvThreads * r];
+            const float pv = pm[THREADS * r];
             acc[r][0] = fmaf(pv, m0, acc[r][0]); acc[r][1] = fmaf(pv, m1, acc[r][1]); acc[r][2] = fmaf(pv, m2, acc[r][2]);
         }
     }
 #pragma unroll
     for (int r = 0; r < kRounds; ++r) {
-        const int k = tid + kInvThreads * r;
+        const int k = tid + THREADS * r;
         if (k < kBins) {
 #pragma unroll
             for (int c = 0; c < 3; ++c)

@@ -16,7 +16,8 @@ __device__ __forceinline__ float wave_max(float v) {
 template <int NFFT> constexpr int stft_smem() { return 4 * NFFT + 8 * 3 * Geo<NFFT>::kTile + 4 * 3 * (Geo<NFFT>::kBins + 7) + 16; }
 
 // One workgroup (192 threads = 3 wavefronts = 3 STFT columns) processes frame `b`.  `smem`: stft_smem<NFFT>() bytes of LDS.
-template <int NFFT, bool WRITE_SPEC, bool WRITE_MEL>
+// THREADS > 192: the extra wavefront helps load / normalise the frame and then waits at the end (the three columns are three waves).
+template <int NFFT, bool WRITE_SPEC, bool WRITE_MEL, int THREADS = kStftThreads>
 __device__ __forceinline__ void stft_body(char* smem, const DspDev& d, const float* __restrict__ frames,
                                           float2* __restrict__ spec, float* __restrict__ mel,
                                           float* __restrict__ peak_out, uint32_t flags, size_t b, int tid) {
@@ -32,17 +33,19 @@ __device__ __forceinline__ void stft_body(char* smem, const DspDev& d, const flo
 
     // ---- P1: load the frame once, find max|x|
     const float4* f4 = reinterpret_cast<const float4*>(frames + b * kNR);
-    float4 q0 = f4[tid];
+    static_assert(kNR / 4 <= 2 * THREADS && THREADS <= 256, "two float4 per thread cover the frame");
+    const bool one = tid < kNR / 4;
+    float4 q0 = one ? f4[tid] : make_float4(0.f, 0.f, 0.f, 0.f);
     float4 q1 = make_float4(0.f, 0.f, 0.f, 0.f);
-    static_assert(kNR / 4 <= 2 * kStftThreads, "two float4 per thread cover the frame");
-    const bool two = tid < (kNR / 4 - kStftThreads);
-    if (two) q1 = f4[tid + kStftThreads];
+    const bool two = tid < (kNR / 4 - THREADS);
+    if (two) q1 = f4[tid + THREADS];
     float mx = fmaxf(fmaxf(fabsf(q0.x), fabsf(q0.y)), fmaxf(fabsf(q0.z), fabsf(q0.w)));
     mx = fmaxf(mx, fmaxf(fmaxf(fabsf(q1.x), fabsf(q1.y)), fmaxf(fabsf(q1.z), fabsf(q1.w))));
     mx = wave_max(mx);
     if (lane == 0) red[w] = mx;
     __syncthreads();
     float pk = fmaxf(red[0], fmaxf(red[1], red[2]));
+    if (THREADS > 192) pk = fmaxf(pk, red[3]);
     const bool norm = (flags & DN_PEAK_NORMALIZE) && pk > 1e-6f;     // app3.py:182
     if (!norm) pk = 1.0f;                                             // app3.py:186
     if (peak_out != nullptr && tid == 0) peak_out[b] = pk;
@@ -57,9 +60,10 @@ __device__ __forceinline__ void stft_body(char* smem, const DspDev& d, const flo
         }
         reinterpret_cast<float4*>(xs)[i4] = q;
     };
-    prep(q0, tid);
-    if (two) prep(q1, tid + kStftThreads);
+    if (one) prep(q0, tid);
+    if (two) prep(q1, tid + THREADS);
     __syncthreads();
+    if (THREADS > 192 && w >= 3) return;          // (no workgroup barrier below this point)
 
     // ---- P4: column w of the centred STFT: padded position p = hop w + n, source i = p - hop reflected
     typename G::Fft::Tw tw;

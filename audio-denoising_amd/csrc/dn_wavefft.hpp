@@ -253,20 +253,21 @@ template <int NFFT> struct Geo {
 // `wkh[t]` = 1/2 W^k for k = lane + 64 t, t = 0..NP-1.
 __device__ __forceinline__ v2f shfl2(v2f v, int src) { return mk2(__shfl(v[0], src), __shfl(v[1], src)); }
 
+// Lane 0 is its own partner and its pairs sit one register further (Z[NC - 64 t] = own v[NV - t]); both directions handle that with
+// per-value selects on the sending / receiving side (v_cndmask), not with a divergent block: a block forces `s_waitcnt lgkmcnt(0)` at its
+// head, i.e. every permute has to be back before the first pair can be combined.
+__device__ __forceinline__ v2f sel2(bool c, v2f a, v2f b) { return mk2(c ? a[0] : b[0], c ? a[1] : b[1]); }
+
 // Forward: v[t] = Z[lane + 64 t] -> lo[t] = X[k], hi[t] = X[NC-k]; mid = X[NC/2] (meaningful in lane 0).
 template <int NV>
 __device__ __forceinline__ void rfft_split_pairs(const v2f (&v)[NV], const v2f (&wkh)[NV / 2], int lane,
                                                  v2f (&lo)[NV / 2], v2f (&hi)[NV / 2], v2f& mid) {
     constexpr int NP = NV / 2;
     const int partner = (64 - lane) & 63;
+    const bool l0 = lane == 0;
     v2f zp[NP];
 #pragma unroll
-    for (int t = 0; t < NP; ++t) zp[t] = shfl2(v[NV - 1 - t], partner);
-    if (lane == 0) {
-        zp[0] = v[0];
-#pragma unroll
-        for (int t = 1; t < NP; ++t) zp[t] = v[NV - t];
-    }
+    for (int t = 0; t < NP; ++t) zp[t] = shfl2(sel2(l0, t == 0 ? v[0] : v[NV - t], v[NV - 1 - t]), partner);
 #pragma unroll
     for (int t = 0; t < NP; ++t) {
         const v2f s = cadd_conj(v[t], zp[t]);                  // Z + conj Zp
@@ -282,7 +283,9 @@ template <int NV>
 __device__ __forceinline__ void irfft_merge_pairs(v2f (&lo)[NV / 2], v2f (&hi)[NV / 2], v2f mid,
                                                   const v2f (&wkh)[NV / 2], int lane, v2f (&v)[NV]) {
     constexpr int NP = NV / 2;
-    if (lane == 0) { lo[0][1] = 0.0f; hi[0][1] = 0.0f; }
+    const bool l0 = lane == 0;
+    lo[0][1] = l0 ? 0.0f : lo[0][1];                           // Im X[0], Im X[NC] are ignored (C2R convention)
+    hi[0][1] = l0 ? 0.0f : hi[0][1];
     v2f zh[NP];
 #pragma unroll
     for (int t = 0; t < NP; ++t) {
@@ -292,13 +295,13 @@ __device__ __forceinline__ void irfft_merge_pairs(v2f (&lo)[NV / 2], v2f (&hi)[N
         zh[t] = chalf_conj_add_iconj(s, dd);                         // conj(s/2) + i conj(dd)
     }
     const int partner = (64 - lane) & 63;
+    v2f r[NP];
 #pragma unroll
-    for (int t = 0; t < NP; ++t) v[NV - 1 - t] = shfl2(zh[t], partner);
-    if (lane == 0) {
+    for (int t = 0; t < NP; ++t) r[t] = shfl2(zh[t], partner);
+    // lanes 1..63: v[NV-1-t] = r[t];  lane 0 (received its own zh): v[NV-t] = r[t] for t >= 1 and v[NP] = conj(mid)
+    const v2f cm = mk2(mid[0], -mid[1]);
 #pragma unroll
-        for (int t = 1; t < NP; ++t) v[NV - t] = zh[t];
-        v[NP] = mk2(mid[0], -mid[1]);
-    }
+    for (int t = 0; t < NP; ++t) v[NV - 1 - t] = sel2(l0, t + 1 < NP ? r[t + 1] : cm, r[t]);
 }
 
 }  // namespace dn

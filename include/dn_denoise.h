@@ -245,6 +245,10 @@ typedef struct dn_pipe dn_pipe;
 int dn_pipe_create(const dn_model* m, const dn_dsp* d, int32_t B, uint32_t flags, dn_pipe** out);
 void dn_pipe_destroy(dn_pipe* p);
 int dn_pipe_set_model(dn_pipe* p, const dn_model* m);
+/* Head start: a front workgroup is done with P1-P10 well before the pending hop's Griffin-Lim chain (same launch) is; with
+ * `iterations` > 0 it goes on with the first iterations of ITS frame's chain and parks it in HBM, and the next launch resumes there.
+ * Same results bit for bit, no added latency; pays when there is about one stream per CU.  Call between launches (0 = off). */
+int dn_pipe_set_head_start(dn_pipe* p, int32_t iterations);
 /* Allocates the per-slot buffers for injected initial phases now (otherwise the first submit/push with init_angles does it):
  * call before capturing a parity-mode launch into a hipGraph, where allocation is not allowed. */
 int dn_pipe_reserve_parity(dn_pipe* p);

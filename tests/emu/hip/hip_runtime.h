@@ -78,6 +78,12 @@ public:
         if (++count_ == n_) { count_ = 0; ++gen_; cv_.notify_all(); }
         else cv_.wait(lk, [&] { return gen_ != g; });
     }
+    // a work-item that has returned no longer counts (as a terminated wavefront does not count at s_barrier)
+    void leave() {
+        std::unique_lock<std::mutex> lk(m_);
+        --n_;
+        if (n_ > 0 && count_ == n_) { count_ = 0; ++gen_; cv_.notify_all(); }
+    }
 };
 
 struct Ctx {
@@ -102,6 +108,8 @@ void launch(K kernel, dim3 grid, dim3 block, A... args) {
                 ctx = Ctx{&bb, wb[t / 64].get(), ws[t / 64].data()};
                 tIdx = dim3(t); bIdx = dim3(bx); bDim = block; gDim = grid;
                 kernel(args...);
+                bb.leave();
+                wb[t / 64]->leave();
             });
         for (auto& x : th) x.join();
     }

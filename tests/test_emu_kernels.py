@@ -360,3 +360,29 @@ def test_momo3_matches_reference_golden(lib, name):
     rc = lib.dn_momo_forward(h, emu.ptr(emu.f32(g["x"])), emu.ptr(emu.f32(g["hx0"])), None, emu.ptr(out), emu.ptr(hx1), None, B, T, F, Cb + 1, None)
     assert rc == -1 and b"compress" in lib.dn_last_error()
     lib.dn_momo_destroy(h)
+
+
+def test_griffinlim_head_start_is_bit_identical(lib, dsp):
+    """dn_pipe_set_head_start: the front workgroup runs the first iterations of its frame's Griffin-Lim chain and parks it in HBM; the
+    next launch resumes.  Cutting the chain at the top of an iteration must not change a bit (frame mode and streaming mode)."""
+    g = load_golden("stream_S.npz")
+    B, n_hops = 2, 3
+    m = make_model(lib, 5)
+    frames = [emu.f32(g["signal"][:B, h * P.hop: h * P.hop + P.n_fft]) for h in range(n_hops)]
+    res = {}
+    for split in (0, 5, 32):
+        pipe = C.c_void_p()
+        lib.check(lib.dn_pipe_create(m, dsp, B, 0, C.byref(pipe)))
+        lib.check(lib.dn_pipe_set_head_start(pipe, split))
+        hx = np.zeros((B, 17, 5), np.float32)
+        outs = [np.zeros((B, P.n_fft), np.float32) for _ in range(n_hops)]
+        for h in range(n_hops):
+            lib.check(lib.dn_pipe_submit(pipe, emu.ptr(frames[h]), emu.ptr(hx), emu.ptr(outs[h]), None, 11, 3, 32, 0.99, None))
+        lib.check(lib.dn_pipe_flush(pipe, 32, 0.99, None))
+        lib.dn_pipe_destroy(pipe)
+        res[split] = (hx, outs)
+    for split in (5, 32):
+        assert np.array_equal(res[0][0], res[split][0])
+        for a, b in zip(res[0][1], res[split][1]):
+            assert np.array_equal(a, b)
+    lib.dn_model_destroy(m)

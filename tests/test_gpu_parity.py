@@ -833,3 +833,38 @@ def test_momo3_conventions_chain_and_errors(dev):
         m(torch.zeros(1, 3, 44, device=dev))                          # 44 bins compress to 5, hx default has 3: shape error as in the reference
     with pytest.raises(RuntimeError):
         m(torch.zeros(1, 3, 22))                                      # CPU tensor: no fallback
+
+
+def test_griffinlim_head_start_is_bit_identical_at_batch_256(dev):
+    """The pipelined hop's head start (front workgroups run the first iterations of their own frame's Griffin-Lim chain and park it in
+    HBM; on by default up to 256 streams) must not change a bit: off, default and a long one give the same frames and the same hx,
+    in frame mode at batch 256 and in streaming mode."""
+    import ctypes as C
+    from audio_denoising_amd.pipeline import Denoiser, HopPipeline, PipelinedStream
+    p = _params("S")
+    dn = Denoiser(_model(dev, 5), p.sample_rate, p.n_fft, p.hop, p.n_mels)
+    g = torch.Generator().manual_seed(77)
+    hops = [(0.1 * torch.randn(256, p.n_fft, generator=g)).to(dev) for _ in range(4)]
+    res = []
+    for split in (0, None, 13):
+        pipe = HopPipeline(dn, 256)
+        if split is not None:
+            dn.lib.check(dn.lib.dn_pipe_set_head_start(pipe.handle, split))
+        hx = dn.init_hx(256)
+        outs = [torch.empty(256, p.n_fft, device=dev) for _ in hops]
+        for i, f in enumerate(hops):
+            pipe.submit(f, hx, outs[i], seed=5, stream_id0=100)
+        pipe.flush()
+        torch.cuda.synchronize()
+        res.append((hx, outs))
+    for hx, outs in res[1:]:
+        assert torch.equal(hx, res[0][0])
+        for a, b in zip(outs, res[0][1]):
+            assert torch.equal(a, b)
+    sres = []
+    for split in (0, 9):
+        ps = PipelinedStream(dn, 8, seed=3)
+        dn.lib.check(dn.lib.dn_pipe_set_head_start(ps.handle, split))
+        o = [ps.push(hops[i][:8, :p.hop].contiguous()) for i in range(4)] + [ps.flush()]
+        sres.append(torch.cat(o, 1))
+    assert torch.equal(sres[0], sres[1])
