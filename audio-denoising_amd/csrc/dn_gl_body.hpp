@@ -108,7 +108,7 @@ __device__ __forceinline__ void gl_body(char* smem, const DspDev& d, const float
 #pragma unroll
         for (int r = 0; r < kRounds; ++r) acc[r][0] = acc[r][1] = acc[r][2] = 0.0f;
         const float* p = d.pinv_t + tid;
-#pragma unroll 4
+#pragma unroll 8
         for (int m = 0; m < M; ++m) {
             const float* pm = p + (size_t)m * d.pinv_stride;
             const float m0 = mm[m], m1 = mm[128 + m], m2 = mm[256 + m];

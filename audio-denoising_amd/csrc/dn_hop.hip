@@ -79,6 +79,15 @@ struct SlotLayout {
 // once.  A front workgroup uses all four: its waves share SIMDs with the Griffin-Lim waves of the same CU (six or seven waves on four
 // SIMDs) and its phases end at workgroup barriers, so the front half -- not the Griffin-Lim chain -- was what ended a batch-256 launch
 // (measured: two iterations moved INTO the front workgroup cost 4.8 us); a fourth wave shortens every conv phase by a quarter.
+#ifdef DN_PROBE
+// diagnostic build only: when the two kinds of workgroups of one launch start and finish (workgroups 0 and back_B of the last launch)
+static __device__ unsigned long long g_hop_wg_probe[8];
+#define DN_HSTAMP(id) do { if (tid == 0 && (blockIdx.x == 0 || (int)blockIdx.x == a.back_B)) { unsigned long long t_; \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); g_hop_wg_probe[id] = t_; } } while (0)
+#else
+#define DN_HSTAMP(id) do { } while (0)
+#endif
+
 template <int NFFT, bool STREAM, bool BF16>
 __global__ __launch_bounds__(kHopPipeThreads, NFFT == 1536 ? 2 : 1) void hop_kernel(DspDev d, CellDev cd, HopArgs a) {
     constexpr int kNR = NFFT, kBins = Geo<NFFT>::kBins;
@@ -92,6 +101,7 @@ __global__ __launch_bounds__(kHopPipeThreads, NFFT == 1536 ? 2 : 1) void hop_ker
     if ((int)blockIdx.x < a.back_B) {
         const size_t b = blockIdx.x;
         if (tid >= kHopThreads) return;         // (before any barrier: a terminated wave no longer counts at s_barrier)
+        DN_HSTAMP(0);
         if (pending) {
             // the Griffin-Lim chain is the critical path of the launch: let its waves win issue arbitration against the
             // front-half waves they share SIMDs with
@@ -111,6 +121,7 @@ __global__ __launch_bounds__(kHopPipeThreads, NFFT == 1536 ? 2 : 1) void hop_ker
                 gl_body<NFFT, false, true>(smem, d, slot + sl.lin, nullptr, init, seed, sid0, slot + sl.peak, nullptr, a.n_iter, a.mom, b, tid,
                                            a.ola, a.hop_out, a.out_s16, it0, -1, st);
             __builtin_amdgcn_s_setprio(0);
+            DN_HSTAMP(1);
         } else if (STREAM) {
             // nothing to emit yet: the reference's ola[:hop] is still zero (app3.py:133,219)
             for (int n = tid; n < kNR / 2; n += kHopThreads) {      // (three waves are left)
@@ -120,6 +131,7 @@ __global__ __launch_bounds__(kHopPipeThreads, NFFT == 1536 ? 2 : 1) void hop_ker
         }
     } else {
         const size_t b = blockIdx.x - a.back_B;
+        DN_HSTAMP(2);
         const float* frames_in = a.frames;
         if (STREAM) {
             ring_shift<NFFT, kHopPipeThreads>(a.ring, a.hop_in, a.in_s16, b, tid);
@@ -134,6 +146,7 @@ __global__ __launch_bounds__(kHopPipeThreads, NFFT == 1536 ? 2 : 1) void hop_ker
             __syncthreads();
             invmel_body<NFFT, true, kHopPipeThreads>(smem, d, slot, slot + sl.diff, slot + sl.lin, 3 * a.B, b * 3, tid);                  // P8-P10
             // what this frame's Griffin-Lim (next launch) needs besides the magnitudes: its seed, its stream ids and, in parity mode, its phases
+            DN_HSTAMP(3);                          // front half (P1-P10) done
             const int split = min(a.gl_split, a.n_iter);
             if (tid == 0) {
                 uint32_t* meta = reinterpret_cast<uint32_t*>(slot + sl.meta) + 8 * b;
@@ -159,6 +172,7 @@ __global__ __launch_bounds__(kHopPipeThreads, NFFT == 1536 ? 2 : 1) void hop_ker
                                             nullptr, nullptr, a.n_iter, a.mom, b, tid, nullptr, nullptr, 0, 0, split,
                                             reinterpret_cast<v2f*>(a.gl_state[s]));
                 __builtin_amdgcn_s_setprio(0);
+                DN_HSTAMP(4);                      // head start done
             }
         }
     }
@@ -256,5 +270,8 @@ void launch_frame(const DspDev& d, const CellDev& c, const FrameArgs& a, int B, 
 // diagnostic build only: the stamps of the Griffin-Lim workgroup 0 of hop_kernel / frame_kernel
 extern "C" int dn_probe_read_hop(unsigned long long* host48) {
     return (int)hipMemcpyFromSymbol(host48, HIP_SYMBOL(dn::g_gl_probe), sizeof(dn::g_gl_probe));
+}
+extern "C" int dn_probe_read_hop_wg(unsigned long long* host8) {
+    return (int)hipMemcpyFromSymbol(host8, HIP_SYMBOL(dn::g_hop_wg_probe), sizeof(dn::g_hop_wg_probe));
 }
 #endif

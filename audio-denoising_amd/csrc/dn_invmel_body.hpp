@@ -33,30 +33,43 @@ __device__ __forceinline__ void invmel_body(char* smem, const DspDev& d, const f
         mm[r][m] = v;
     }
     __syncthreads();
-    // thread <-> bins tid, tid+192, ..: independent load streams (pinv_t rows are zero padded to a multiple of 192)
-    constexpr int kRounds = (kBins + THREADS - 1) / THREADS;
-    float acc[kRounds][3];
+    // thread <-> bins tid, tid+THREADS, ..: independent load streams over the transposed pseudo-inverse (rows zero padded, so every load
+    // of a full round is in bounds).  n_fft/2 + 1 bins = whole rounds + a few left-over bins (ONE for 256 threads): those get a loop of
+    // their own that only the wavefront owning them runs, instead of a padded round in which every thread loads zeros.
+    constexpr int kFull = kBins / THREADS, kRem = kBins - kFull * THREADS;
+    float acc[kFull][3];
 #pragma unroll
-    for (int r = 0; r < kRounds; ++r) acc[r][0] = acc[r][1] = acc[r][2] = 0.0f;
+    for (int r = 0; r < kFull; ++r) acc[r][0] = acc[r][1] = acc[r][2] = 0.0f;
     const float* p = d.pinv_t + tid;
-#pragma unroll 4
+#pragma unroll 8
     for (int m = 0; m < M; ++m) {
         const float* pm = p + (size_t)m * d.pinv_stride;
         const float m0 = mm[0][m], m1 = mm[1][m], m2 = mm[2][m];
 #pragma unroll
-        for (int r = 0; r < kRounds; ++r) {
+        for (int r = 0; r < kFull; ++r) {
             const float pv = pm[THREADS * r];
             acc[r][0] = fmaf(pv, m0, acc[r][0]); acc[r][1] = fmaf(pv, m1, acc[r][1]); acc[r][2] = fmaf(pv, m2, acc[r][2]);
         }
     }
 #pragma unroll
-    for (int r = 0; r < kRounds; ++r) {
+    for (int r = 0; r < kFull; ++r) {
         const int k = tid + THREADS * r;
-        if (k < kBins) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c)
-                if (r0 + c < (size_t)rows) lin[(r0 + c) * kBins + k] = fmaxf(acc[r][c], 0.0f);
+        for (int c = 0; c < 3; ++c)
+            if (r0 + c < (size_t)rows) lin[(r0 + c) * kBins + k] = fmaxf(acc[r][c], 0.0f);
+    }
+    if (kRem > 0 && tid < kRem) {
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+        const float* pr = p + THREADS * kFull;
+#pragma unroll 8
+        for (int m = 0; m < M; ++m) {
+            const float pv = pr[(size_t)m * d.pinv_stride];
+            a0 = fmaf(pv, mm[0][m], a0); a1 = fmaf(pv, mm[1][m], a1); a2 = fmaf(pv, mm[2][m], a2);
         }
+        const int k = tid + THREADS * kFull;
+        if (r0 + 0 < (size_t)rows) lin[(r0 + 0) * kBins + k] = fmaxf(a0, 0.0f);
+        if (r0 + 1 < (size_t)rows) lin[(r0 + 1) * kBins + k] = fmaxf(a1, 0.0f);
+        if (r0 + 2 < (size_t)rows) lin[(r0 + 2) * kBins + k] = fmaxf(a2, 0.0f);
     }
 }
 
