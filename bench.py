@@ -457,7 +457,11 @@ def main():
 
     ingress = None
     if world > 1 and pipe is not None:
-        ingress = ingress_variant(dn, pipe, B, world, rank, dev, lo, args.steps, args.warmup, dist, backend, fence, on_gpu)
+        # a side measurement must never cost the headline line: any failure in it (on every rank alike: the loop is collective) is reported, not raised
+        try:
+            ingress = ingress_variant(dn, pipe, B, world, rank, dev, lo, args.steps, args.warmup, dist, backend, fence, on_gpu)
+        except Exception as e:          # noqa: BLE001
+            ingress = {"ingress": "scatter_gather", "error": f"{type(e).__name__}: {e}"[:300]}
 
     line = None
     if rank == 0:
