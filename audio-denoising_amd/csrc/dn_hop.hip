@@ -29,6 +29,9 @@ constexpr int kHopPipeThreads = 256;      // workgroup size of the fused launche
 #ifndef DN_GL_PRIO
 #define DN_GL_PRIO 3
 #endif
+#ifndef DN_HS_PRIO
+#define DN_HS_PRIO 1
+#endif
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 template <int NFFT> constexpr int hop_smem() { return cmax(cmax(kCellSmem, gl_smem<NFFT>()), cmax(stft_smem<NFFT>(), kInvSmem)); }
 static_assert(kHopThreads == kGlThreads && kHopThreads == kStftThreads && kHopThreads == kInvThreads, "one block size for all bodies");
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(kHopPipeThreads, NFFT == 1536 ? 2 : 1) void hop_ker
                 // head start: this workgroup would idle for the rest of the launch (the pending hop's chain is ~1.5x longer than P1-P10)
                 __syncthreads();                       // the magnitudes are in the slot
                 if (tid >= kHopThreads) return;        // the chain is three waves wide
-                __builtin_amdgcn_s_setprio(1);         // below the pending hop's chain (3): that one ends the launch
+                __builtin_amdgcn_s_setprio(DN_HS_PRIO); // below the pending hop's chain (3): that one ends the launch
                 gl_body<NFFT, false, false>(smem, d, slot + sl.lin, nullptr, reinterpret_cast<const v2f*>(a.init_in), a.seed + frames, a.sid0,
                                             nullptr, nullptr, a.n_iter, a.mom, b, tid, nullptr, nullptr, 0, 0, split,
                                             reinterpret_cast<v2f*>(a.gl_state[s]));
