@@ -91,7 +91,8 @@ static __device__ unsigned long long g_hop_wg_probe[8];
 #define DN_HSTAMP(id) do { } while (0)
 #endif
 
-template <int NFFT, bool STREAM, bool BF16>
+// CT: the number of compressed mel bins when the plan has the usual one (80 mels at n_fft 1024, 64 at 1536), 0 = any (run-time lengths in the model)
+template <int NFFT, bool STREAM, bool BF16, int CT>
 __global__ __launch_bounds__(kHopPipeThreads, NFFT == 1536 ? 2 : 1) void hop_kernel(DspDev d, CellDev cd, HopArgs a) {
     constexpr int kNR = NFFT, kBins = Geo<NFFT>::kBins;
     __shared__ __attribute__((aligned(16))) char smem[hop_smem<NFFT>()];
@@ -145,8 +146,10 @@ __global__ __launch_bounds__(kHopPipeThreads, NFFT == 1536 ? 2 : 1) void hop_ker
             float* slot = a.slot[s];
             stft_body<NFFT, false, true, kHopPipeThreads>(smem, d, frames_in, nullptr, slot, slot + sl.peak, DN_PEAK_NORMALIZE | DN_PRE_WINDOW, b, tid);   // P1-P6
             __syncthreads();
-            cell_body<kHopPipeThreads / 64, BF16>(smem, cd, slot, a.hx, slot + sl.diff, a.hx, 3, a.C, b, tid);                            // P7
+            DN_HSTAMP(5);
+            cell_body<kHopPipeThreads / 64, BF16, CT>(smem, cd, slot, a.hx, slot + sl.diff, a.hx, 3, a.C, b, tid);                        // P7
             __syncthreads();
+            DN_HSTAMP(6);
             invmel_body<NFFT, true, kHopPipeThreads>(smem, d, slot, slot + sl.diff, slot + sl.lin, 3 * a.B, b * 3, tid);                  // P8-P10
             // what this frame's Griffin-Lim (next launch) needs besides the magnitudes: its seed, its stream ids and, in parity mode, its phases
             DN_HSTAMP(3);                          // front half (P1-P10) done
@@ -203,8 +206,14 @@ __global__ __launch_bounds__(kHopPipeThreads, NFFT == 1536 ? 2 : 1) void hop_ker
 template <int NFFT, bool STREAM>
 static void launch_hop_n(const DspDev& d, const CellDev& c, const HopArgs& a, bool bf16, hipStream_t st) {
     const dim3 grid(a.back_B + a.front_B), block(kHopPipeThreads);
-    if (bf16) hipLaunchKernelGGL((hop_kernel<NFFT, STREAM, true>), grid, block, 0, st, d, c, a);
-    else hipLaunchKernelGGL((hop_kernel<NFFT, STREAM, false>), grid, block, 0, st, d, c, a);
+    constexpr int kUsualC = NFFT == 1536 ? 4 : 5;
+    if (a.C == kUsualC) {
+        if (bf16) hipLaunchKernelGGL((hop_kernel<NFFT, STREAM, true, kUsualC>), grid, block, 0, st, d, c, a);
+        else hipLaunchKernelGGL((hop_kernel<NFFT, STREAM, false, kUsualC>), grid, block, 0, st, d, c, a);
+    } else {
+        if (bf16) hipLaunchKernelGGL((hop_kernel<NFFT, STREAM, true, 0>), grid, block, 0, st, d, c, a);
+        else hipLaunchKernelGGL((hop_kernel<NFFT, STREAM, false, 0>), grid, block, 0, st, d, c, a);
+    }
 }
 
 void launch_hop(const DspDev& d, const CellDev& c, const HopArgs& a, bool bf16, hipStream_t st) {
@@ -227,7 +236,7 @@ void launch_ctl_set(PipeCtl* ctl, unsigned long long pushes, unsigned long long 
 
 // ---- the unpipelined hop: P1-P12 of one stream in one workgroup, one launch per hop (zero added latency).  Four wavefronts for the
 // front half (the conv phases split four ways), three for the Griffin-Lim chain behind it (the fourth exits).
-template <int NFFT, bool STREAM, bool BF16>
+template <int NFFT, bool STREAM, bool BF16, int CT>
 __global__ __launch_bounds__(kHopPipeThreads, NFFT == 1536 ? 2 : 1) void frame_kernel(DspDev d, CellDev cd, FrameArgs a) {
     __shared__ __attribute__((aligned(16))) char smem[hop_smem<NFFT>()];
     const int tid = threadIdx.x;
@@ -239,7 +248,7 @@ __global__ __launch_bounds__(kHopPipeThreads, NFFT == 1536 ? 2 : 1) void frame_k
     }
     stft_body<NFFT, false, true, kHopPipeThreads>(smem, d, frames_in, nullptr, a.mel, a.peak, DN_PEAK_NORMALIZE | DN_PRE_WINDOW, b, tid);   // P1-P6
     __syncthreads();
-    cell_body<kHopPipeThreads / 64, BF16>(smem, cd, a.mel, a.hx, a.diff, a.hx, 3, a.C, b, tid);                                          // P7
+    cell_body<kHopPipeThreads / 64, BF16, CT>(smem, cd, a.mel, a.hx, a.diff, a.hx, 3, a.C, b, tid);                                      // P7
     __syncthreads();
     if (tid >= kHopThreads) return;
     // P8-P12: the inverse-mel contraction is the Griffin-Lim prologue (the linear magnitudes stay in LDS)
@@ -252,8 +261,14 @@ __global__ __launch_bounds__(kHopPipeThreads, NFFT == 1536 ? 2 : 1) void frame_k
 
 template <int NFFT, bool STREAM>
 static void launch_frame_n(const DspDev& d, const CellDev& c, const FrameArgs& a, int B, bool bf16, hipStream_t st) {
-    if (bf16) hipLaunchKernelGGL((frame_kernel<NFFT, STREAM, true>), dim3(B), dim3(kHopPipeThreads), 0, st, d, c, a);
-    else hipLaunchKernelGGL((frame_kernel<NFFT, STREAM, false>), dim3(B), dim3(kHopPipeThreads), 0, st, d, c, a);
+    constexpr int kUsualC = NFFT == 1536 ? 4 : 5;
+    if (a.C == kUsualC) {
+        if (bf16) hipLaunchKernelGGL((frame_kernel<NFFT, STREAM, true, kUsualC>), dim3(B), dim3(kHopPipeThreads), 0, st, d, c, a);
+        else hipLaunchKernelGGL((frame_kernel<NFFT, STREAM, false, kUsualC>), dim3(B), dim3(kHopPipeThreads), 0, st, d, c, a);
+    } else {
+        if (bf16) hipLaunchKernelGGL((frame_kernel<NFFT, STREAM, true, 0>), dim3(B), dim3(kHopPipeThreads), 0, st, d, c, a);
+        else hipLaunchKernelGGL((frame_kernel<NFFT, STREAM, false, 0>), dim3(B), dim3(kHopPipeThreads), 0, st, d, c, a);
+    }
 }
 
 void launch_frame(const DspDev& d, const CellDev& c, const FrameArgs& a, int B, bool bf16, hipStream_t st) {

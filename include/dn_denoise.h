@@ -248,7 +248,7 @@ int dn_pipe_set_model(dn_pipe* p, const dn_model* m);
 /* Head start: a front workgroup is done with P1-P10 well before the pending hop's Griffin-Lim chain (same launch) is; with
  * `iterations` > 0 it goes on with the first iterations of ITS frame's chain and parks it in HBM, and the next launch resumes there.
  * Same results bit for bit, no added latency; pays when there is about one stream per CU.  dn_pipe_create turns it on by itself up to
- * 256 streams (3 iterations at n_fft 1024, 6 at 1536).  Call between launches (0 = off). */
+ * 256 streams (4 iterations at n_fft 1024, 7 at 1536).  Call between launches (0 = off). */
 int dn_pipe_set_head_start(dn_pipe* p, int32_t iterations);
 /* Allocates the per-slot buffers for injected initial phases now (otherwise the first submit/push with init_angles does it):
  * call before capturing a parity-mode launch into a hipGraph, where allocation is not allowed. */

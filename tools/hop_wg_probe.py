@@ -25,7 +25,7 @@ for i in range(300):
 torch.cuda.synchronize()
 buf = (C.c_uint64 * 8)()
 assert dn.lib.lib.dn_probe_read_hop_wg(buf) == 0
-t = [buf[i] for i in range(5)]
+t = [buf[i] for i in range(7)]
 t0 = min(t[0], t[2])
 print(f"head start {os.environ.get('DN_GL_HEAD_START', 'default')}: Griffin-Lim WG 0: start {t[0] - t0}, end {t[1] - t0};  "
-      f"front WG 0: start {t[2] - t0}, P1-P10 done {t[3] - t0}, head start done {t[4] - t0 if t[4] > t[2] else '-'}  (ticks)")
+      f"front WG 0: start {t[2] - t0}, stft done {t[5] - t0}, cell done {t[6] - t0}, P1-P10 done {t[3] - t0}, head start done {t[4] - t0 if t[4] > t[2] else '-'}  (ticks)")
