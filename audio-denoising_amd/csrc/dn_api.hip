@@ -45,6 +45,7 @@ struct DevArena {
         return off;
     }
     hipError_t upload() {
+        host.resize(host.size() + dn::kArenaSlack);     // zeros: kernels that move whole rounds of an array read past its end (dn_cell_body.hpp)
         size = host.size();
         hipError_t e = hipMalloc(reinterpret_cast<void**>(&base), size ? size : 256);
         if (e != hipSuccess) return e;

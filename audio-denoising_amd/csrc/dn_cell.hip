@@ -29,12 +29,13 @@ namespace dn {
 
 constexpr int kCellWaves = 4;
 
-template <int CT>
+// CT / TC: the compressed bin count and the number of time steps when they are the usual ones (5 or 4 bins, the hop's 3 columns), 0 = run time
+template <int CT, int TC>
 __global__ __launch_bounds__(kCellWaves * 64) void cell_kernel(CellDev cd, const float* __restrict__ x,
                                                               const float* __restrict__ hx_in, float* __restrict__ out,
                                                               float* __restrict__ hx_out, int T, int C) {
     __shared__ __attribute__((aligned(16))) char smem[kCellSmem];
-    cell_body<kCellWaves, false, CT>(smem, cd, x, hx_in, out, hx_out, T, C, blockIdx.x, threadIdx.x);
+    cell_body<kCellWaves, false, CT>(smem, cd, x, hx_in, out, hx_out, TC ? TC : T, C, blockIdx.x, threadIdx.x);
 }
 
 // BASELINE config 3: the same forward with bf16 MFMA conv tiles (v_mfma_f32_16x16x32_bf16; conv inputs and weights
@@ -48,9 +49,10 @@ __global__ __launch_bounds__(kCellWaves * 64) void cell_kernel_bf16(CellDev cd, 
 
 void launch_cell(const CellDev& c, const float* x, const float* hx_in, float* out, float* hx_out, int B, int T,
                  int C, hipStream_t st) {
-    if (C == 5) hipLaunchKernelGGL(cell_kernel<5>, dim3(B), dim3(kCellWaves * 64), 0, st, c, x, hx_in, out, hx_out, T, C);
-    else if (C == 4) hipLaunchKernelGGL(cell_kernel<4>, dim3(B), dim3(kCellWaves * 64), 0, st, c, x, hx_in, out, hx_out, T, C);
-    else hipLaunchKernelGGL(cell_kernel<0>, dim3(B), dim3(kCellWaves * 64), 0, st, c, x, hx_in, out, hx_out, T, C);
+    auto k = cell_kernel<0, 0>;
+    if (C == 5) k = T == kCellChunk ? cell_kernel<5, kCellChunk> : cell_kernel<5, 0>;
+    else if (C == 4) k = T == kCellChunk ? cell_kernel<4, kCellChunk> : cell_kernel<4, 0>;
+    hipLaunchKernelGGL(k, dim3(B), dim3(kCellWaves * 64), 0, st, c, x, hx_in, out, hx_out, T, C);
 }
 
 __global__ __launch_bounds__(kCellWaves * 64) void cell_kernel_ex(CellDev cd, const float* __restrict__ x,

@@ -17,18 +17,70 @@ static __device__ unsigned long long g_cell_probe[32];
         if (b == 0 && tid == 0) g_cell_probe[id] = t_;                                            \
         __builtin_amdgcn_sched_barrier(0);                                                        \
     } while (0)
+// the same from inside a conv tile of the level under the magnifying glass (DN_PROBE_LEVEL: CIN * 100 + COUT of an encoder level)
+#define DN_CSTAMP_IN(id)                                                                          \
+    do {                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        unsigned long long t_;                                                                    \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");               \
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_cell_probe[id] = t_;                           \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+    } while (0)
 #else
 #define DN_CSTAMP(id) do { } while (0)
+#define DN_CSTAMP_IN(id) do { } while (0)
 #endif
+
+// Rows 16 mt + 4 q + r (r = 0..3) of one accumulator tile -> relu -> dst[row * stride]; see the note on exec-mask regions below.
+template <int COUT>
+__device__ __forceinline__ void store_rows(const f32x4& acc, float* dst, int stride, int mt, int q, float* trash) {
+    constexpr int kRows = COUT % 16;                 // rows of the last row tile when it is a partial one
+    if (kRows == 0 || (mt + 1) * 16 <= COUT) {       // wave-uniform
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[(mt * 16 + q * 4 + r) * stride] = fmaxf(acc[r], 0.0f);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (r >= kRows) continue;                // 4 q + r >= r
+            float* d = 4 * q + r < kRows ? dst + (mt * 16 + q * 4 + r) * stride : trash;
+            *d = fmaxf(acc[r], 0.0f);
+        }
+    }
+}
+template <int COUT>
+__device__ __forceinline__ void store_rows2(const f32x4& ev, const f32x4& od, float* dst, int stride, int mt, int q, float* trash) {
+    constexpr int kRows = COUT % 16;
+    if (kRows == 0 || (mt + 1) * 16 <= COUT) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            *reinterpret_cast<float2*>(dst + (mt * 16 + q * 4 + r) * stride) = make_float2(fmaxf(ev[r], 0.0f), fmaxf(od[r], 0.0f));
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (r >= kRows) continue;
+            float* d = 4 * q + r < kRows ? dst + (mt * 16 + q * 4 + r) * stride : trash;
+            *reinterpret_cast<float2*>(d) = make_float2(fmaxf(ev[r], 0.0f), fmaxf(od[r], 0.0f));
+        }
+    }
+}
 
 // ---- Conv1d k3 s2 p1 (+ folded position bias, relu) as an MFMA contraction.
 //   in [TT][CIN][2*lout] (LDS) -> out [TT][COUT][lout] (LDS)
 //   afrag: [MTILES][KS][64] weight fragments, K order = tap-major, channels in groups of 4
 //          (CIN = 1: one k-step whose 4 K slots are the 3 taps + a zero)
 //   work split: tile = (n-tile of 16 items) x (group of MT m-tiles); tiles are dealt to waves round robin.
+//
+// The levels are issue bound, not MFMA bound (a phase is a few hundred instructions of one wavefront around 15-60 MFMAs), so the
+// tiles avoid exec-mask regions (four scalar instructions and a branch each):
+//   * lanes past the last item work on item 0 again and hold exactly item 0's results -- their stores rewrite the same values;
+//   * accumulator rows that do not exist (o >= COUT) start from the last real row's bias and are never stored;
+//   * the rows of the last, partial row tile that do not exist are stored to `trash` (an LDS word nobody reads): a select on the
+//     address instead of a predicated store;
+//   * operands next to an edge are loaded unconditionally (one word outside the buffer at most, still inside the LDS plan) and
+//     zeroed by a select.
 template <int NW, int CIN, int COUT, int MT>
 __device__ __forceinline__ void mconv_down(const float* afrag, const float* bt, const float* in,
-                                           float* out, int lout, int tt, int wv, int lane) {
+                                           float* out, float* trash, int lout, int tt, int wv, int lane) {
     constexpr int CS = (CIN + 3) / 4;
     constexpr int KS = CIN == 1 ? 1 : 3 * CS;
     constexpr int MTILES = (COUT + 15) / 16;
@@ -47,17 +99,21 @@ __device__ __forceinline__ void mconv_down(const float* afrag, const float* bt, 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int o = (mt0 + mi) * 16 + q * 4 + r;
-                acc[mi][r] = o < COUT ? bt[o * lout + p] : 0.0f;
+                acc[mi][r] = bt[min(o, COUT - 1) * lout + p];
             }
         const float* af = afrag + (size_t)mt0 * KS * 64 + lane;
         if (CIN == 1) {
             const int idx = t * lin + 2 * p - 1 + q;
             const bool ok = q < 3 && !(q == 0 && p == 0);
-            const float b = ok ? in[idx] : 0.0f;
+            float b = in[idx];
+            b = ok ? b : 0.0f;
 #pragma unroll
             for (int mi = 0; mi < MT; ++mi) acc[mi] = mfma16(af[mi * KS * 64], b, acc[mi]);
         } else {
+            // every operand of the tile is requested before the first MFMA: fetched a k-step at a time, each step paid an LDS round
+            // trip (~150 cycles) in front of its 32-cycle MFMA
             const float* base = in + (size_t)t * CIN * lin + 2 * p - 1;
+            float bv[KS], av[MT][KS];
 #pragma unroll
             for (int tap = 0; tap < 3; ++tap)
 #pragma unroll
@@ -65,20 +121,22 @@ __device__ __forceinline__ void mconv_down(const float* afrag, const float* bt, 
                     const int c = min(4 * cs + q, CIN - 1);          // padded K slots carry zero weights
                     float b = base[c * lin + tap];
                     if (tap == 0 && p == 0) b = 0.0f;                // left zero padding of the conv
-                    const int ks = tap * CS + cs;
-#pragma unroll
-                    for (int mi = 0; mi < MT; ++mi) acc[mi] = mfma16(af[(mi * KS + ks) * 64], b, acc[mi]);
+                    bv[tap * CS + cs] = b;
                 }
-        }
-        if (valid) {
 #pragma unroll
             for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int o = (mt0 + mi) * 16 + q * 4 + r;
-                    if (o < COUT) out[((size_t)t * COUT + o) * lout + p] = fmaxf(acc[mi][r], 0.0f);
-                }
+                for (int ks = 0; ks < KS; ++ks) av[mi][ks] = af[(mi * KS + ks) * 64];
+            __builtin_amdgcn_sched_barrier(0);
+            if (CIN == kHidden && COUT == kHidden && MT == 2) DN_CSTAMP_IN(18);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi) acc[mi] = mfma16(av[mi][ks], bv[ks], acc[mi]);
+            if (CIN == kHidden && COUT == kHidden && MT == 2) DN_CSTAMP_IN(19);
         }
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) store_rows<COUT>(acc[mi], out + (size_t)t * COUT * lout + p, lout, mt0 + mi, q, trash);
     }
 }
 
@@ -91,7 +149,7 @@ __device__ __forceinline__ f32x4 mfma16_bf16(const bf16x8& a, const bf16x8& b, f
 
 template <int NW, int CIN, int COUT, int MT>
 __device__ __forceinline__ void mconv_down_bf16(const void* afrag, const float* bt, const float* in,
-                                                float* out, int lout, int tt, int wv, int lane) {
+                                                float* out, float* trash, int lout, int tt, int wv, int lane) {
     constexpr int KS = CIN == 1 ? 1 : 3;
     constexpr int MTILES = (COUT + 15) / 16;
     constexpr int MG = MTILES / MT;
@@ -110,14 +168,15 @@ __device__ __forceinline__ void mconv_down_bf16(const void* afrag, const float* 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int o = (mt0 + mi) * 16 + q * 4 + r;
-                acc[mi][r] = o < COUT ? bt[o * lout + p] : 0.0f;
+                acc[mi][r] = bt[min(o, COUT - 1) * lout + p];
             }
         if (CIN == 1) {
             bf16x8 b;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const bool ok = q == 0 && j < 3 && !(j == 0 && p == 0);
-                b[j] = f2bf(ok ? in[t * lin + 2 * p - 1 + j] : 0.0f);
+                const float x = j < 3 ? in[t * lin + 2 * p - 1 + j] : 0.0f;
+                b[j] = f2bf(ok ? x : 0.0f);
             }
 #pragma unroll
             for (int mi = 0; mi < MT; ++mi) acc[mi] = mfma16_bf16(af8[((mt0 + mi) * KS) * 64 + lane], b, acc[mi]);
@@ -137,21 +196,14 @@ __device__ __forceinline__ void mconv_down_bf16(const void* afrag, const float* 
                 for (int mi = 0; mi < MT; ++mi) acc[mi] = mfma16_bf16(af8[((mt0 + mi) * KS + tap) * 64 + lane], b, acc[mi]);
             }
         }
-        if (valid) {
 #pragma unroll
-            for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int o = (mt0 + mi) * 16 + q * 4 + r;
-                    if (o < COUT) out[((size_t)t * COUT + o) * lout + p] = fmaxf(acc[mi][r], 0.0f);
-                }
-        }
+        for (int mi = 0; mi < MT; ++mi) store_rows<COUT>(acc[mi], out + (size_t)t * COUT * lout + p, lout, mt0 + mi, q, trash);
     }
 }
 
 template <int NW, bool SKIP, int MT>
 __device__ __forceinline__ void mconv_up_bf16(const void* afrag, const float* bt, const float* a,
-                                              const float* skip, float* out, int l, int tt, int wv, int lane) {
+                                              const float* skip, float* out, float* trash, int l, int tt, int wv, int lane) {
     constexpr int PARTS = SKIP ? 2 : 1;
     constexpr int MTILES = 2, MG = MTILES / MT;
     const bf16x8* af8 = static_cast<const bf16x8*>(afrag);
@@ -169,9 +221,10 @@ __device__ __forceinline__ void mconv_up_bf16(const void* afrag, const float* bt
         for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int o = (mt0 + mi) * 16 + q * 4 + r;
-                ev[mi][r] = o < kHidden ? bt[o * lo + 2 * i] : 0.0f;
-                od[mi][r] = o < kHidden ? bt[o * lo + 2 * i + 1] : 0.0f;
+                const int o = min((mt0 + mi) * 16 + q * 4 + r, kHidden - 1);
+                const float2 bb = *reinterpret_cast<const float2*>(bt + o * lo + 2 * i);
+                ev[mi][r] = bb.x;
+                od[mi][r] = bb.y;
             }
 #pragma unroll
         for (int part = 0; part < PARTS; ++part) {
@@ -182,8 +235,9 @@ __device__ __forceinline__ void mconv_up_bf16(const void* afrag, const float* bt
                 const int c = 8 * q + j;
                 const bool ok = c < kHidden;
                 const float* sc = src + min(c, kHidden - 1) * l;
-                x0[j] = f2bf(ok ? sc[0] : 0.0f);
-                x1[j] = f2bf(ok && has_next ? sc[1] : 0.0f);
+                const float s0 = sc[0], s1 = sc[1];
+                x0[j] = f2bf(ok ? s0 : 0.0f);
+                x1[j] = f2bf(ok && has_next ? s1 : 0.0f);
             }
 #pragma unroll
             for (int mi = 0; mi < MT; ++mi) {
@@ -193,17 +247,9 @@ __device__ __forceinline__ void mconv_up_bf16(const void* afrag, const float* bt
                 od[mi] = mfma16_bf16(am[2 * PARTS * 64], x1, od[mi]);
             }
         }
-        if (valid) {
 #pragma unroll
-            for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int o = (mt0 + mi) * 16 + q * 4 + r;
-                    if (o < kHidden)
-                        *reinterpret_cast<float2*>(out + ((size_t)t * kHidden + o) * lo + 2 * i) =
-                            make_float2(fmaxf(ev[mi][r], 0.0f), fmaxf(od[mi][r], 0.0f));
-                }
-        }
+        for (int mi = 0; mi < MT; ++mi)
+            store_rows2<kHidden>(ev[mi], od[mi], out + (size_t)t * kHidden * lo + 2 * i, lo, mt0 + mi, q, trash);
     }
 }
 
@@ -214,7 +260,8 @@ __device__ __forceinline__ void mconv_up_bf16(const void* afrag, const float* bt
 // afrag: [MTILES=2][3 tap sets: k=1, k=2, k=0][KSU][64]; K order = part-major (a, then skip), channels in fours.
 template <int NW, bool SKIP, int MT, int COUT = kHidden, bool LAST = false>
 __device__ __forceinline__ void mconv_up(const float* afrag, const float* bt, const float* a,
-                                         const float* skip, float* out, int l, int tt, int wv, int lane, size_t out_t_stride = 0) {
+                                         const float* skip, float* out, float* trash, int l, int tt, int wv, int lane,
+                                         size_t out_t_stride = 0) {
     constexpr int CS = 5;                      // ceil(17 / 4)
     constexpr int KSU = SKIP ? 2 * CS : CS;
     constexpr int MTILES = (COUT + 15) / 16, MG = MTILES / MT;
@@ -232,43 +279,47 @@ __device__ __forceinline__ void mconv_up(const float* afrag, const float* bt, co
         for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int o = (mt0 + mi) * 16 + q * 4 + r;
-                ev[mi][r] = o < COUT ? bt[o * lo + 2 * i] : 0.0f;
-                od[mi][r] = o < COUT ? bt[o * lo + 2 * i + 1] : 0.0f;
+                const int o = min((mt0 + mi) * 16 + q * 4 + r, COUT - 1);
+                const float2 bb = *reinterpret_cast<const float2*>(bt + o * lo + 2 * i);
+                ev[mi][r] = bb.x;
+                od[mi][r] = bb.y;
             }
         const float* af = afrag + (size_t)mt0 * 3 * KSU * 64 + lane;
 #pragma unroll
         for (int part = 0; part < (SKIP ? 2 : 1); ++part) {
+            // all operands of one part (a, then skip) are requested before its first MFMA (see mconv_down)
             const float* src = (part == 0 ? a : skip) + (size_t)t * kHidden * l + i;
+            float x0[CS], x1[CS], av[MT][3][CS];
 #pragma unroll
             for (int cs = 0; cs < CS; ++cs) {
                 const int c = min(4 * cs + q, kHidden - 1);
-                const float x0 = src[c * l];
-                const float x1 = has_next ? src[c * l + 1] : 0.0f;
-                const int ks = part * CS + cs;
-#pragma unroll
-                for (int mi = 0; mi < MT; ++mi) {
-                    const float* am = af + (size_t)mi * 3 * KSU * 64;
-                    ev[mi] = mfma16(am[(0 * KSU + ks) * 64], x0, ev[mi]);
-                    od[mi] = mfma16(am[(1 * KSU + ks) * 64], x0, od[mi]);
-                    od[mi] = mfma16(am[(2 * KSU + ks) * 64], x1, od[mi]);
-                }
+                x0[cs] = src[c * l];
+                const float xn = src[c * l + 1];
+                x1[cs] = has_next ? xn : 0.0f;
             }
-        }
-        if (valid) {
 #pragma unroll
             for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int o = (mt0 + mi) * 16 + q * 4 + r;
-                    if (o < COUT) {
-                        if (LAST)      // the last level is linear and its single channel is the model output row (gruunet2.py:94-96, 242)
-                            *reinterpret_cast<float2*>(out + (size_t)t * out_t_stride + 2 * i) = make_float2(ev[mi][r], od[mi][r]);
-                        else
-                            *reinterpret_cast<float2*>(out + ((size_t)t * COUT + o) * lo + 2 * i) =
-                                make_float2(fmaxf(ev[mi][r], 0.0f), fmaxf(od[mi][r], 0.0f));
-                    }
+                for (int set = 0; set < 3; ++set)
+#pragma unroll
+                    for (int cs = 0; cs < CS; ++cs) av[mi][set][cs] = af[((size_t)(mi * 3 + set) * KSU + part * CS + cs) * 64];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int cs = 0; cs < CS; ++cs)
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi) {
+                    ev[mi] = mfma16(av[mi][0][cs], x0[cs], ev[mi]);
+                    od[mi] = mfma16(av[mi][1][cs], x0[cs], od[mi]);
+                    od[mi] = mfma16(av[mi][2][cs], x1[cs], od[mi]);
                 }
+        }
+        if (LAST) {    // the last level is linear and its single channel (row 0 of the one row tile) is the model output row (gruunet2.py:94-96, 242)
+            static_assert(!LAST || (COUT == 1 && MT == 1), "last level: one output channel");
+            if (q == 0) *reinterpret_cast<float2*>(out + (size_t)t * out_t_stride + 2 * i) = make_float2(ev[0][0], od[0][0]);
+        } else {
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+                store_rows2<COUT>(ev[mi], od[mi], out + (size_t)t * COUT * lo + 2 * i, lo, mt0 + mi, q, trash);
         }
     }
 }
@@ -280,7 +331,7 @@ struct CellLds {
     int x, d0, d1, d2, d3, h, gh, hi, u0, u1, u2, total;
     __host__ __device__ explicit CellLds(int C) {
         const int T = kCellChunk, F = 16 * C;
-        int o = 4;                            // words 0..3: guard in front of the first buffer (index -1 reads)
+        int o = 8;                            // words 0..3: trash (stores of rows that do not exist); 4..7: zero guard in front of the first buffer (index -1 reads)
         x = o;  o += T * F;
         d0 = o; o += T * kHidden * 8 * C;
         d1 = o; o += T * kHidden * 4 * C;
@@ -296,23 +347,28 @@ struct CellLds {
     }
 };
 
-constexpr int kCellActFloats = 4 + 3 * 16 * kMaxC + 3 * 17 * 14 * kMaxC * 2 + 3 * 51 * kMaxC + 17 * kMaxC + 51 * kMaxC + 3 * 17 * kMaxC;
+constexpr int kCellActFloats = 8 + 3 * 16 * kMaxC + 3 * 17 * 14 * kMaxC * 2 + 3 * 51 * kMaxC + 17 * kMaxC + 51 * kMaxC + 3 * 17 * kMaxC;
 // Weight fragments and bias tables are staged through LDS one level ahead (double buffered): while level L multiplies, every
 // thread has level L+1's share of fragments in flight from L2 and drops it into the other buffer before the barrier.  The
 // levels are a strictly serial chain of short phases (~1 us each): with the fragments fetched at the head of every phase the
 // kernel spent 71 % of its time in s_waitcnt (profiles/r01_v4_pmc_sq.txt); staged, a phase starts on LDS-resident operands.
-constexpr int kCellWFloats = 4 * 15 * 64;        // largest level: 51 -> 4 row tiles x 15 k-steps (= 2 x 3 x 10 of a skip decoder level)
-constexpr int kCellBFloats = kHidden * 8 * kMaxC;  // largest bias table: 17 channels x 8C positions
+constexpr int kCellWFloats = 4096;               // largest level: 51 -> 4 row tiles x 15 k-steps x 64 = 3840 (= 2 x 3 x 10 x 64 of a skip decoder level), in whole rounds
+constexpr int kCellBFloats = 768;                // largest bias table: 17 channels x 8C positions = 680 at C = 5, in whole rounds
 constexpr int kCellLdsFloats = kCellActFloats + 2 * kCellWFloats + 2 * kCellBFloats;
-constexpr int kCellSmem = 4 * kCellLdsFloats;      // 71,136 B
+constexpr int kCellSmem = 4 * kCellLdsFloats;
+static_assert(kCellActFloats % 4 == 0, "fragment buffers are written 16 bytes at a time");
 
 // One level's operands in HBM/L2: weight fragments (fp32 or bf16, counted in floats) and the bias table.
 struct CellLevel { const float* w; int wn; const float* b; int bn; };
 
-template <int THREADS>
+// A round = one load per thread (16 bytes of fragments / 4 bytes of bias).  With the sizes known at compile time (CT != 0; PAD) the
+// stager moves WHOLE rounds: every load and every LDS store is unconditional, the tail of the last round reads what follows the
+// array in its arena (the arenas end in a slack of kArenaSlack bytes) and lands in buffer space nobody reads.
+template <int THREADS, bool PAD>
 struct CellStager {
-    static constexpr int kW4 = (kCellWFloats / 4 + THREADS - 1) / THREADS;     // float4 per thread (5 at 192 threads)
-    static constexpr int kB1 = (kCellBFloats + THREADS - 1) / THREADS;         // floats per thread (4)
+    static constexpr int kW4 = (kCellWFloats / 4 + THREADS - 1) / THREADS;     // float4 per thread
+    static constexpr int kB1 = (kCellBFloats + THREADS - 1) / THREADS;         // floats per thread
+    static_assert(!PAD || (kW4 * THREADS * 4 <= kCellWFloats && kB1 * THREADS <= kCellBFloats), "whole rounds must fit the buffers");
     float4 w[kW4];
     float b[kB1];
     __device__ __forceinline__ void issue(const CellLevel& lv, int tid) {
@@ -320,24 +376,24 @@ struct CellStager {
 #pragma unroll
         for (int i = 0; i < kW4; ++i) {
             const int j = tid + THREADS * i;
-            w[i] = 4 * j < lv.wn ? w4[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+            w[i] = (PAD ? 4 * THREADS * i < lv.wn : 4 * j < lv.wn) ? w4[j] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int i = 0; i < kB1; ++i) {
             const int j = tid + THREADS * i;
-            b[i] = j < lv.bn ? lv.b[j] : 0.0f;
+            b[i] = (PAD ? THREADS * i < lv.bn : j < lv.bn) ? lv.b[j] : 0.0f;
         }
     }
     __device__ __forceinline__ void commit(const CellLevel& lv, float* wbuf, float* bbuf, int tid) const {
 #pragma unroll
         for (int i = 0; i < kW4; ++i) {
             const int j = tid + THREADS * i;
-            if (4 * j < lv.wn) reinterpret_cast<float4*>(wbuf)[j] = w[i];
+            if (PAD ? 4 * THREADS * i < lv.wn : 4 * j < lv.wn) reinterpret_cast<float4*>(wbuf)[j] = w[i];
         }
 #pragma unroll
         for (int i = 0; i < kB1; ++i) {
             const int j = tid + THREADS * i;
-            if (j < lv.bn) bbuf[j] = b[i];
+            if (PAD ? THREADS * i < lv.bn : j < lv.bn) bbuf[j] = b[i];
         }
     }
 };
@@ -385,12 +441,13 @@ __device__ __forceinline__ void cell_body(char* smem, const CellDev& cd, const f
     };
     // two register sets: level L+2 is requested while level L multiplies and level L+1 (requested a phase earlier) is dropped
     // into its buffer -- every request has more than a whole phase to come back from L2
-    CellStager<kCellThreads> stgA, stgB;
+    CellStager<kCellThreads, CT != 0 && kCellThreads == 256> stgA, stgB;
     stgA.issue(level(0), tid);
     stgB.issue(level(1), tid);
 
     DN_CSTAMP(0);
-    if (tid < 4) lds[tid] = 0.0f;
+    if (tid < 8) lds[tid] = 0.0f;
+    float* trash = lds;
     // hidden state -> LDS (gruunet2.py:294-301: zeros when the caller passes none)
     for (int i = tid; i < kHidden * C; i += kCellThreads) sh[i] = hx_in != nullptr ? hx_in[b * kHidden * C + i] : 0.0f;
 
@@ -446,26 +503,29 @@ __device__ __forceinline__ void cell_body(char* smem, const CellDev& cd, const f
         DN_CSTAMP(1);
         // ---- encoder, batched over the chunk (gruunet2.py:136-144); level i multiplies out of buffer i & 1
         stgA.issue(level(2), tid);
-        if (BF16) mconv_down_bf16<NW, 1, kHidden, 2>(wbuf[0], bbuf[0], sx, sd0, 8 * C, tt, wv, lane);
-        else mconv_down<NW, 1, kHidden, 2>(wbuf[0], bbuf[0], sx, sd0, 8 * C, tt, wv, lane);
+        if (BF16) mconv_down_bf16<NW, 1, kHidden, 2>(wbuf[0], bbuf[0], sx, sd0, trash, 8 * C, tt, wv, lane);
+        else mconv_down<NW, 1, kHidden, 2>(wbuf[0], bbuf[0], sx, sd0, trash, 8 * C, tt, wv, lane);
         stgB.commit(level(1), wbuf[1], bbuf[1], tid);
         DN_LDS_BARRIER();
         DN_CSTAMP(2);
         stgB.issue(level(3), tid);
-        if (BF16) mconv_down_bf16<NW, kHidden, kHidden, 2>(wbuf[1], bbuf[1], sd0, sd1, 4 * C, tt, wv, lane);
-        else mconv_down<NW, kHidden, kHidden, 2>(wbuf[1], bbuf[1], sd0, sd1, 4 * C, tt, wv, lane);
+        DN_CSTAMP(17);
+        if (BF16) mconv_down_bf16<NW, kHidden, kHidden, 2>(wbuf[1], bbuf[1], sd0, sd1, trash, 4 * C, tt, wv, lane);
+        else mconv_down<NW, kHidden, kHidden, 2>(wbuf[1], bbuf[1], sd0, sd1, trash, 4 * C, tt, wv, lane);
+        DN_CSTAMP(20);
         stgA.commit(level(2), wbuf[0], bbuf[0], tid);
+        DN_CSTAMP(21);
         DN_LDS_BARRIER();
         DN_CSTAMP(3);
         stgA.issue(level(4), tid);
-        if (BF16) mconv_down_bf16<NW, kHidden, kHidden, 1>(wbuf[0], bbuf[0], sd1, sd2, 2 * C, tt, wv, lane);
-        else mconv_down<NW, kHidden, kHidden, 1>(wbuf[0], bbuf[0], sd1, sd2, 2 * C, tt, wv, lane);
+        if (BF16) mconv_down_bf16<NW, kHidden, kHidden, 1>(wbuf[0], bbuf[0], sd1, sd2, trash, 2 * C, tt, wv, lane);
+        else mconv_down<NW, kHidden, kHidden, 1>(wbuf[0], bbuf[0], sd1, sd2, trash, 2 * C, tt, wv, lane);
         stgB.commit(level(3), wbuf[1], bbuf[1], tid);
         DN_LDS_BARRIER();
         DN_CSTAMP(4);
         stgB.issue(level(5), tid);
-        if (BF16) mconv_down_bf16<NW, kHidden, kGates, 1>(wbuf[1], bbuf[1], sd2, sd3, C, tt, wv, lane);
-        else mconv_down<NW, kHidden, kGates, 1>(wbuf[1], bbuf[1], sd2, sd3, C, tt, wv, lane);
+        if (BF16) mconv_down_bf16<NW, kHidden, kGates, 1>(wbuf[1], bbuf[1], sd2, sd3, trash, C, tt, wv, lane);
+        else mconv_down<NW, kHidden, kGates, 1>(wbuf[1], bbuf[1], sd2, sd3, trash, C, tt, wv, lane);
         stgA.commit(level(4), wbuf[0], bbuf[0], tid);
         DN_LDS_BARRIER();
         DN_CSTAMP(5);
@@ -476,14 +536,19 @@ __device__ __forceinline__ void cell_body(char* smem, const CellDev& cd, const f
                 f32x4 acc[kGhTiles];
 #pragma unroll
                 for (int g = 0; g < kGhTiles; ++g) acc[g] = bgh[g];
+                float bv[kGhKS];
 #pragma unroll
                 for (int ks = 0; ks < kGhKS; ++ks) {
                     const int kk = 4 * ks + q, c = kk / 3, k = kk - 3 * c, src = p - 1 + k;
-                    const float bv = (c < kHidden && p < C && src >= 0 && src < C) ? sh[c * C + src] : 0.0f;
+                    const float v = sh[c * C + src];   // at most one word in front of / a few behind `sh`: inside the plan
+                    bv[ks] = (c < kHidden && p < C && src >= 0 && src < C) ? v : 0.0f;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ks = 0; ks < kGhKS; ++ks)
 #pragma unroll
                     for (int g = 0; g < kGhTiles; ++g)
-                        if (wv + NW * g < 4) acc[g] = mfma16(agh[g][ks], bv, acc[g]);
-                }
+                        if (wv + NW * g < 4) acc[g] = mfma16(agh[g][ks], bv[ks], acc[g]);
 #pragma unroll
                 for (int g = 0; g < kGhTiles; ++g)
 #pragma unroll
@@ -511,26 +576,26 @@ __device__ __forceinline__ void cell_body(char* smem, const CellDev& cd, const f
         }
         // ---- decoder, batched over the chunk (gruunet2.py:184-199); skips are d2, d1, d0 (the last level has no cat)
         stgA.issue(level(6), tid);
-        if (BF16) mconv_up_bf16<NW, false, 1>(wbuf[0], bbuf[0], shi, nullptr, su0, C, tt, wv, lane);
-        else mconv_up<NW, false, 1>(wbuf[0], bbuf[0], shi, nullptr, su0, C, tt, wv, lane);
+        if (BF16) mconv_up_bf16<NW, false, 1>(wbuf[0], bbuf[0], shi, nullptr, su0, trash, C, tt, wv, lane);
+        else mconv_up<NW, false, 1>(wbuf[0], bbuf[0], shi, nullptr, su0, trash, C, tt, wv, lane);
         DN_LDS_BARRIER();
         DN_CSTAMP(9);
-        if (BF16) mconv_up_bf16<NW, true, 1>(wbuf[1], bbuf[1], su0, sd2, su1, 2 * C, tt, wv, lane);
-        else mconv_up<NW, true, 1>(wbuf[1], bbuf[1], su0, sd2, su1, 2 * C, tt, wv, lane);
+        if (BF16) mconv_up_bf16<NW, true, 1>(wbuf[1], bbuf[1], su0, sd2, su1, trash, 2 * C, tt, wv, lane);
+        else mconv_up<NW, true, 1>(wbuf[1], bbuf[1], su0, sd2, su1, trash, 2 * C, tt, wv, lane);
         stgA.commit(level(6), wbuf[0], bbuf[0], tid);
         DN_LDS_BARRIER();
         DN_CSTAMP(10);
         const bool more = t0 + kCellChunk < T;
         if (more) stgA.issue(level(0), tid);
-        if (BF16) mconv_up_bf16<NW, true, 2>(wbuf[0], bbuf[0], su1, sd1, su2, 4 * C, tt, wv, lane);
-        else mconv_up<NW, true, 2>(wbuf[0], bbuf[0], su1, sd1, su2, 4 * C, tt, wv, lane);
+        if (BF16) mconv_up_bf16<NW, true, 2>(wbuf[0], bbuf[0], su1, sd1, su2, trash, 4 * C, tt, wv, lane);
+        else mconv_up<NW, true, 2>(wbuf[0], bbuf[0], su1, sd1, su2, trash, 4 * C, tt, wv, lane);
         stgB.commit(level(7), wbuf[1], bbuf[1], tid);
         DN_LDS_BARRIER();
         DN_CSTAMP(11);
         // last level: one output channel (one row tile, 15 of its 16 rows idle), exact fp32 MFMA in both precisions; its rows are
         // the model output.  The next chunk's first levels are on their way meanwhile.
         if (more) stgB.issue(level(1), tid);
-        mconv_up<NW, true, 1, 1, true>(wbuf[1], bbuf[1], su2, sd0, out + (b * T + t0) * F, 8 * C, tt, wv, lane, (size_t)F);
+        mconv_up<NW, true, 1, 1, true>(wbuf[1], bbuf[1], su2, sd0, out + (b * T + t0) * F, trash, 8 * C, tt, wv, lane, (size_t)F);
     }
     __syncthreads();
     DN_CSTAMP(12);

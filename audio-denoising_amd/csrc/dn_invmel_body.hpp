@@ -11,6 +11,12 @@ constexpr int kMaxMels = 128;
 
 constexpr int kInvSmem = 4 * kInvRows * kMaxMels;
 
+#ifndef DN_INVMEL_UNROLL
+#define DN_INVMEL_UNROLL 8
+#endif
+#define DN_PRAGMA_(x) _Pragma(#x)
+#define DN_PRAGMA(x) DN_PRAGMA_(x)
+
 // One workgroup (192 threads) handles rows r0 .. r0+2 (the three columns of one stream).  `smem`: kInvSmem bytes.
 template <int NFFT, bool RESIDUAL, int THREADS = kInvThreads>
 __device__ __forceinline__ void invmel_body(char* smem, const DspDev& d, const float* __restrict__ x,
@@ -41,7 +47,7 @@ __device__ __forceinline__ void invmel_body(char* smem, const DspDev& d, const f
 #pragma unroll
     for (int r = 0; r < kFull; ++r) acc[r][0] = acc[r][1] = acc[r][2] = 0.0f;
     const float* p = d.pinv_t + tid;
-#pragma unroll 8
+DN_PRAGMA(unroll DN_INVMEL_UNROLL)
     for (int m = 0; m < M; ++m) {
         const float* pm = p + (size_t)m * d.pinv_stride;
         const float m0 = mm[0][m], m1 = mm[1][m], m2 = mm[2][m];

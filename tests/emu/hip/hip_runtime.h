@@ -139,6 +139,7 @@ inline unsigned int atomicAdd(unsigned int* p, unsigned int v) { unsigned int o 
 #define __builtin_amdgcn_wave_barrier() dn_emu::ctx.wave->wait()
 #define __builtin_amdgcn_readfirstlane(x) (x)
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
 inline float __shfl_xor(float v, int mask) { return dn_emu::shfl(v, (int)(dn_emu::tIdx.x & 63) ^ mask); }
 inline float __shfl(float v, int src) { return dn_emu::shfl(v, src); }
 using std::max;

@@ -30,6 +30,9 @@ def main():
     print(f"cell forward batch {batch}: {tot} ticks")
     for i, n in enumerate(NAMES):
         print(f"    {n:28s} {t[i + 1] - t[i]:6d}  {100.0 * (t[i + 1] - t[i]) / tot:5.1f} %")
+    f = [buf[i] for i in range(17, 22)]
+    print(f"  inside d1, wave 0: stage requests {f[0] - t[2]}, bias + operand loads {f[1] - f[0]}, 30 MFMAs issued {f[2] - f[1]}, "
+          f"results + stores {f[3] - f[2]}, stage commit {f[4] - f[3]}, barrier {t[3] - f[4]}")
 
 
 if __name__ == "__main__":
