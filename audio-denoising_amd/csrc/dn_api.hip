@@ -312,8 +312,16 @@ int dn_model_create(const float* weights, size_t n_floats, const dn_model_cfg* c
         m->off_gh = m->packed.add(p.data(), p.size() * sizeof(float));
     }
     for (int l = 0; l < 4; ++l) {   // ConvTranspose1d weight (Ct, Cout, 3) -> [mt][tap set: k=1,k=2,k=0][ks][64], parts of 17 channels in fours
-        const int parts = l == 0 ? 1 : 2, co = l == 3 ? 1 : 17, ksu = parts * 5, mtiles = (co + 15) / 16;   // last level: one channel = one row tile
         static const int kTapOfSet[3] = {1, 2, 0};
+        if (l == 3) {   // the last level (one output channel) runs on the VALU: [part: a, skip][17 channels][4] = w[k=1], w[k=2], w[k=0], 0
+            std::vector<float> p((size_t)2 * 17 * 4, 0.0f);
+            for (int part = 0; part < 2; ++part)
+                for (int c = 0; c < 17; ++c)
+                    for (int set = 0; set < 3; ++set) p[((size_t)part * 17 + c) * 4 + set] = W[sl.uw[3] + ((size_t)(part * 17 + c)) * 3 + kTapOfSet[set]];
+            m->off_up[l] = m->packed.add(p.data(), p.size() * sizeof(float));
+            continue;
+        }
+        const int parts = l == 0 ? 1 : 2, co = 17, ksu = parts * 5, mtiles = (co + 15) / 16;
         std::vector<float> p((size_t)mtiles * 3 * ksu * 64, 0.0f);
         for (int mt = 0; mt < mtiles; ++mt)
             for (int set = 0; set < 3; ++set)

@@ -258,10 +258,9 @@ __device__ __forceinline__ void mconv_up_bf16(const void* afrag, const float* bt
 // Item = (t, input position i):  out[2i]   = sum_c w[c][o][1] x[c][i]
 //                                out[2i+1] = sum_c w[c][o][2] x[c][i] + w[c][o][0] x[c][i+1]
 // afrag: [MTILES=2][3 tap sets: k=1, k=2, k=0][KSU][64]; K order = part-major (a, then skip), channels in fours.
-template <int NW, bool SKIP, int MT, int COUT = kHidden, bool LAST = false>
+template <int NW, bool SKIP, int MT, int COUT = kHidden>
 __device__ __forceinline__ void mconv_up(const float* afrag, const float* bt, const float* a,
-                                         const float* skip, float* out, float* trash, int l, int tt, int wv, int lane,
-                                         size_t out_t_stride = 0) {
+                                         const float* skip, float* out, float* trash, int l, int tt, int wv, int lane) {
     constexpr int CS = 5;                      // ceil(17 / 4)
     constexpr int KSU = SKIP ? 2 * CS : CS;
     constexpr int MTILES = (COUT + 15) / 16, MG = MTILES / MT;
@@ -313,14 +312,44 @@ __device__ __forceinline__ void mconv_up(const float* afrag, const float* bt, co
                     od[mi] = mfma16(av[mi][2][cs], x1[cs], od[mi]);
                 }
         }
-        if (LAST) {    // the last level is linear and its single channel (row 0 of the one row tile) is the model output row (gruunet2.py:94-96, 242)
-            static_assert(!LAST || (COUT == 1 && MT == 1), "last level: one output channel");
-            if (q == 0) *reinterpret_cast<float2*>(out + (size_t)t * out_t_stride + 2 * i) = make_float2(ev[0][0], od[0][0]);
-        } else {
 #pragma unroll
-            for (int mi = 0; mi < MT; ++mi)
-                store_rows2<COUT>(ev[mi], od[mi], out + (size_t)t * COUT * lo + 2 * i, lo, mt0 + mi, q, trash);
-        }
+        for (int mi = 0; mi < MT; ++mi)
+            store_rows2<COUT>(ev[mi], od[mi], out + (size_t)t * COUT * lo + 2 * i, lo, mt0 + mi, q, trash);
+    }
+}
+
+// ---- the last decoder level (ConvTranspose1d 34 -> 1, linear: gruunet2.py:94-96, 242) on the VALU.  One output channel is one
+// useful row of a 16-row MFMA tile: as a contraction it cost 60 MFMAs a wavefront (1,920 cycles) for 120 x 2 outputs.  Here a thread
+// owns one item (t, input position i) and one half of the input channels (a: wavefronts 0-1, skip: wavefronts 2-3): 17 channels x
+// 3 taps of FMAs on operands read straight from LDS (weights: one broadcast 16-byte read per channel), the skip half handed over
+// through `part`.  wt: [2 parts][17][4] = w[k=1], w[k=2], w[k=0], 0.
+template <int NW>
+__device__ __forceinline__ void last_up(const float* wt, const float* bt, const float* a, const float* skip, float* out,
+                                        float* part, int l, int tt, int tid, size_t out_t_stride) {
+    static_assert(NW == 4, "two wavefronts per half of the channels");
+    const int h = tid >> 7, item = tid & 127, items = tt * l;      // items <= 3 * 8 * kMaxC = 120
+    const int itc = item < items ? item : 0;
+    const int t = itc / l, i = itc - t * l;
+    const bool has_next = i + 1 < l;
+    const float* src = (h == 0 ? a : skip) + (size_t)t * kHidden * l + i;
+    const float4* w4 = reinterpret_cast<const float4*>(wt) + h * kHidden;
+    float ev = 0.0f, od = 0.0f;
+#pragma unroll
+    for (int c = 0; c < kHidden; ++c) {
+        const float4 w = w4[c];
+        const float x0 = src[c * l];
+        float x1 = src[c * l + 1];
+        x1 = has_next ? x1 : 0.0f;
+        ev = fmaf(w.x, x0, ev);
+        od = fmaf(w.y, x0, od);
+        od = fmaf(w.z, x1, od);
+    }
+    if (h == 1) *reinterpret_cast<float2*>(part + 2 * item) = make_float2(ev, od);
+    DN_LDS_BARRIER();
+    if (h == 0 && item < items) {
+        const float2 ps = *reinterpret_cast<const float2*>(part + 2 * item);
+        const float2 bb = *reinterpret_cast<const float2*>(bt + 2 * i);
+        *reinterpret_cast<float2*>(out + (size_t)t * out_t_stride + 2 * i) = make_float2(bb.x + (ev + ps.x), bb.y + (od + ps.y));
     }
 }
 
@@ -433,7 +462,7 @@ __device__ __forceinline__ void cell_body(char* smem, const CellDev& cd, const f
             const int l = i - 4, parts = l == 0 ? 1 : 2;
             const bool bf = BF16 && l < 3;                        // the single-channel last level stays fp32
             lv.w = bf ? static_cast<const float*>(cd.wb_up[l]) : cd.w_up[l];
-            lv.wn = bf ? 2 * 3 * parts * 64 * 4 : (l == 3 ? 1 : 2) * 3 * parts * 5 * 64;
+            lv.wn = bf ? 2 * 3 * parts * 64 * 4 : l == 3 ? 2 * kHidden * 4 : 2 * 3 * parts * 5 * 64;
             lv.b = cd.bt_up[l];
             lv.bn = (l == 3 ? 1 : kHidden) * (2 * C << l);
         }
@@ -567,10 +596,6 @@ __device__ __forceinline__ void cell_body(char* smem, const CellDev& cd, const f
                 sh[tid] = hn;
                 shi[t * kHidden * C + tid] = hn;
             }
-            if (t == 0) {
-                stgB.commit(level(5), wbuf[1], bbuf[1], tid);
-                stgB.issue(level(7), tid);
-            }
             DN_LDS_BARRIER();
             DN_CSTAMP(6 + t);
         }
@@ -578,6 +603,8 @@ __device__ __forceinline__ void cell_body(char* smem, const CellDev& cd, const f
         stgA.issue(level(6), tid);
         if (BF16) mconv_up_bf16<NW, false, 1>(wbuf[0], bbuf[0], shi, nullptr, su0, trash, C, tt, wv, lane);
         else mconv_up<NW, false, 1>(wbuf[0], bbuf[0], shi, nullptr, su0, trash, C, tt, wv, lane);
+        stgB.commit(level(5), wbuf[1], bbuf[1], tid);      // requested four phases ago (buffer 1 has been free since the last encoder level)
+        stgB.issue(level(7), tid);
         DN_LDS_BARRIER();
         DN_CSTAMP(9);
         if (BF16) mconv_up_bf16<NW, true, 1>(wbuf[1], bbuf[1], su0, sd2, su1, trash, 2 * C, tt, wv, lane);
@@ -592,10 +619,10 @@ __device__ __forceinline__ void cell_body(char* smem, const CellDev& cd, const f
         stgB.commit(level(7), wbuf[1], bbuf[1], tid);
         DN_LDS_BARRIER();
         DN_CSTAMP(11);
-        // last level: one output channel (one row tile, 15 of its 16 rows idle), exact fp32 MFMA in both precisions; its rows are
-        // the model output.  The next chunk's first levels are on their way meanwhile.
+        // last level: one output channel, VALU, fp32 in both precisions; its rows are the model output.  The next chunk's first levels
+        // are on their way meanwhile.  (`su0` has been dead since the second decoder level: it carries the skip half's partial sums.)
         if (more) stgB.issue(level(1), tid);
-        mconv_up<NW, true, 1, 1, true>(wbuf[1], bbuf[1], su2, sd0, out + (b * T + t0) * F, trash, 8 * C, tt, wv, lane, (size_t)F);
+        last_up<NW>(wbuf[1], bbuf[1], su2, sd0, out + (b * T + t0) * F, su0, 8 * C, tt, tid, (size_t)F);
     }
     __syncthreads();
     DN_CSTAMP(12);

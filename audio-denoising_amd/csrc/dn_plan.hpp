@@ -28,7 +28,7 @@ struct CellDev {
     // Encoder / decoder weights are stored as v_mfma_f32_16x16x4_f32 A fragments in lane order (dn_cell.hip):
     //   w_down[l]: [m-tile][k-step][64]          K = taps x channels-in-fours (level 0: the 3 taps)
     //   w_up[l<3]: [m-tile][tap set][k-step][64]  tap sets k=1 (even outputs), k=2 and k=0 (odd outputs)
-    //   w_up[3]  : the same layout with ONE m-tile (single output channel)
+    //   w_up[3]  : the single-output-channel last level runs on the VALU: [part: a, skip][17][4] = w[k=1], w[k=2], w[k=0], 0
     const float* w_down[4];  // data channels 1,17,17,17 -> 17,17,17,51
     const float* w_gh;       // [m-tile 4][k-step 13][64]  hidden-gate conv fragments, K slot = 3 c + tap (held in VGPRs across time steps)
     const float* w_up[4];    // data channels 17,34,34,34 -> 17,17,17,1
