@@ -461,7 +461,7 @@ int dn_dsp_create(const dn_dsp_cfg* cfg, const float* fb_in, const float* pinv_i
     size_t o_tw512 = d->arena.add(tw512.data(), tw512.size() * 4), o_tw1024 = d->arena.add(tw1024.data(), tw1024.size() * 4);
     size_t o_win = d->arena.add(d->window.data(), N * 4), o_env = d->arena.add(inv_env.data(), N * 4);
     size_t o_ms = 0, o_ml = 0, o_mw = 0, o_pinv = 0;
-    int maxlen = 0;
+    int maxlen = 0, passlen[2] = {0, 0};
     const int pstride = ((K + 767) / 768) * 768;      // the contraction kernels stream rows in rounds of 192 or 256 bins (zero padded: tail loads stay in bounds)
     if (M > 0) {
         d->fb.resize((size_t)K * M);
@@ -488,6 +488,7 @@ int dn_dsp_create(const dn_dsp_cfg* cfg, const float* fb_in, const float* pinv_i
             start[mm] = hi < 0 ? 0 : lo;
             len[mm] = hi < 0 ? 0 : hi - lo + 1;
             maxlen = len[mm] > maxlen ? len[mm] : maxlen;
+            if (mm < 128) passlen[mm / 64] = len[mm] > passlen[mm / 64] ? len[mm] : passlen[mm / 64];
         }
         std::vector<float> mw((size_t)(maxlen ? maxlen : 1) * M, 0.0f);
         for (int mm = 0; mm < M; ++mm)
@@ -527,6 +528,7 @@ int dn_dsp_create(const dn_dsp_cfg* cfg, const float* fb_in, const float* pinv_i
     v.inv_env = d->arena.ptr<float>(o_env);
     v.n_mels = M;
     v.mel_maxlen = maxlen;
+    v.mel_passlen[0] = passlen[0]; v.mel_passlen[1] = passlen[1];
     v.pinv_stride = pstride;
     v.mel_start = M ? d->arena.ptr<int>(o_ms) : nullptr;
     v.mel_len = M ? d->arena.ptr<int>(o_ml) : nullptr;
@@ -781,6 +783,10 @@ int dn_pipe_set_head_start(dn_pipe* p, int32_t iterations) {
         const size_t nv = (size_t)p->d->cfg.n_fft / 128;       // complex values per lane
         const size_t bytes = (size_t)p->B * 3 * (2 * nv + 2) * 64 * sizeof(float2);
         for (int i = 0; i < 2; ++i) DN_HIP(hipMalloc(reinterpret_cast<void**>(&p->gl_state[i]), bytes));
+    }
+    if (iterations > 0) {      // the head start reads its frame's initial phases from the slot (the front workgroup's spare wave draws them)
+        int rc = dn_pipe_reserve_parity(p);
+        if (rc != DN_OK) return rc;
     }
     p->gl_split = iterations;
     return DN_OK;

@@ -98,7 +98,7 @@ __device__ __forceinline__ void gl_body(char* smem, const DspDev& d, const float
             const int c = i / M, m = i - c * M;
             float v = mag[(b * 3 + c) * M + m] - diff[(b * 3 + c) * M + m];
             v = v >= 0.0f ? v : 0.2f * v;              // leaky_relu, app3.py:204
-            mm[c * 128 + m] = fmaxf(expm1f(v), 0.0f);  // app3.py:207-208
+            mm[c * 128 + m] = fmaxf(fast_expm1(v), 0.0f);  // app3.py:207-208 (as dn_invmel_body.hpp)
         }
         __syncthreads();
         // thread <-> bins tid, tid+192, ..: each pinv element is loaded once and used for all 3 columns (pinv_t rows are

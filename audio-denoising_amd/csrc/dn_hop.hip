@@ -145,6 +145,19 @@ __global__ __launch_bounds__(kHopPipeThreads, NFFT == 1536 ? 2 : 1) void hop_ker
             const int s = (int)(frames & 1);
             float* slot = a.slot[s];
             stft_body<NFFT, false, true, kHopPipeThreads>(smem, d, frames_in, nullptr, slot, slot + sl.peak, DN_PEAK_NORMALIZE | DN_PRE_WINDOW, b, tid);   // P1-P6
+            const int split = min(a.gl_split, a.n_iter);
+            const bool draw = split > 0 && a.init_in == nullptr;
+            if (draw && tid >= kHopThreads) {
+                // The fourth wave has no column to transform and would wait here: it draws the random initial phases the head start
+                // below begins with (the same Philox blocks, so the same bits) into the slot.  One block per bin is ~10 rounds of
+                // quarter-rate integer multiplies -- 9 bins a lane cost the head start ~7 k cycles on the launch's critical path.
+                float2* dst = a.slot_init[s] + b * 3 * kBins;
+                for (int i = tid - kHopThreads; i < 3 * kBins; i += 64) {
+                    const int col = i / kBins, k = i - col * kBins;
+                    const v2f r = rand_angle(a.seed + frames, a.sid0 + b, col, k);
+                    dst[i] = make_float2(r[0], r[1]);
+                }
+            }
             __syncthreads();
             DN_HSTAMP(5);
             cell_body<kHopPipeThreads / 64, BF16, CT>(smem, cd, slot, a.hx, slot + sl.diff, a.hx, 3, a.C, b, tid);                        // P7
@@ -153,7 +166,6 @@ __global__ __launch_bounds__(kHopPipeThreads, NFFT == 1536 ? 2 : 1) void hop_ker
             invmel_body<NFFT, true, kHopPipeThreads>(smem, d, slot, slot + sl.diff, slot + sl.lin, 3 * a.B, b * 3, tid);                  // P8-P10
             // what this frame's Griffin-Lim (next launch) needs besides the magnitudes: its seed, its stream ids and, in parity mode, its phases
             DN_HSTAMP(3);                          // front half (P1-P10) done
-            const int split = min(a.gl_split, a.n_iter);
             if (tid == 0) {
                 uint32_t* meta = reinterpret_cast<uint32_t*>(slot + sl.meta) + 8 * b;
                 const uint64_t seed = a.seed + frames;
@@ -174,7 +186,8 @@ __global__ __launch_bounds__(kHopPipeThreads, NFFT == 1536 ? 2 : 1) void hop_ker
                 __syncthreads();                       // the magnitudes are in the slot
                 if (tid >= kHopThreads) return;        // the chain is three waves wide
                 __builtin_amdgcn_s_setprio(DN_HS_PRIO); // below the pending hop's chain (3): that one ends the launch
-                gl_body<NFFT, false, false>(smem, d, slot + sl.lin, nullptr, reinterpret_cast<const v2f*>(a.init_in), a.seed + frames, a.sid0,
+                gl_body<NFFT, false, false>(smem, d, slot + sl.lin, nullptr,
+                                            draw ? reinterpret_cast<const v2f*>(a.slot_init[s]) : reinterpret_cast<const v2f*>(a.init_in), a.seed + frames, a.sid0,
                                             nullptr, nullptr, a.n_iter, a.mom, b, tid, nullptr, nullptr, 0, 0, split,
                                             reinterpret_cast<v2f*>(a.gl_state[s]));
                 __builtin_amdgcn_s_setprio(0);
@@ -291,5 +304,11 @@ extern "C" int dn_probe_read_hop(unsigned long long* host48) {
 }
 extern "C" int dn_probe_read_hop_wg(unsigned long long* host8) {
     return (int)hipMemcpyFromSymbol(host8, HIP_SYMBOL(dn::g_hop_wg_probe), sizeof(dn::g_hop_wg_probe));
+}
+extern "C" int dn_probe_read_hop_stft(unsigned long long* host8) {
+    return (int)hipMemcpyFromSymbol(host8, HIP_SYMBOL(dn::g_stft_probe), sizeof(dn::g_stft_probe));
+}
+extern "C" int dn_probe_read_hop_invmel(unsigned long long* host8) {
+    return (int)hipMemcpyFromSymbol(host8, HIP_SYMBOL(dn::g_inv_probe), sizeof(dn::g_inv_probe));
 }
 #endif

@@ -29,6 +29,56 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define DN_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #endif
 
+// Wave-wide max / sum, the result in every lane.  On the device: six DPP steps on the VALU (row_shr 1, 2, 4, 8, then the row
+// broadcasts 15 and 31 leave the total in lane 63) -- __shfl_xor compiles to ds_bpermute, an LDS round trip of ~230 cycles a step.
+// The CPU emulation tier (tests/emu) has no DPP and defines DN_WAVE_REDUCE_SHFL.
+#ifdef DN_WAVE_REDUCE_SHFL
+__device__ __forceinline__ float wave_max(float v) {
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+#else
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_take(float v) {       // lanes without a source keep their own value
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = fmaxf(v, dpp_take<0x111, 0xf>(v));     // row_shr:1
+    v = fmaxf(v, dpp_take<0x112, 0xf>(v));     // row_shr:2
+    v = fmaxf(v, dpp_take<0x114, 0xf>(v));     // row_shr:4
+    v = fmaxf(v, dpp_take<0x118, 0xf>(v));     // row_shr:8   -> lane 15 of every row of 16 holds the row's max
+    v = fmaxf(v, dpp_take<0x142, 0xa>(v));     // row_bcast:15 into rows 1 and 3
+    v = fmaxf(v, dpp_take<0x143, 0xc>(v));     // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's max
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+// (the shifted-in operand must be 0 where a lane has no source: `old` = 0 with the lane's own value added outside)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_take0(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v += dpp_take0<0x111, 0xf>(v);
+    v += dpp_take0<0x112, 0xf>(v);
+    v += dpp_take0<0x114, 0xf>(v);
+    v += dpp_take0<0x118, 0xf>(v);
+    v += dpp_take0<0x142, 0xa>(v);
+    v += dpp_take0<0x143, 0xc>(v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+#endif
+
+// Elementwise transcendentals of the front half on the hardware units (v_exp_f32 / v_log_f32 / v_sqrt_f32 / v_rcp_f32, 1 ulp each)
+// instead of libm's correctly rounded sequences (30-130 instructions a call).  The front workgroup shares its SIMDs with a Griffin-Lim
+// chain that wins issue arbitration, so it pays ~11 cycles per instruction it issues: these calls were ~600 of its instructions.
+// Absolute errors ~1e-7 relative to values of order 1-10 (log-mel features, linear magnitudes), against a parity tolerance of 1e-4.
+__device__ __forceinline__ float fast_log1p(float x) { return __builtin_amdgcn_logf(1.0f + x) * 0.693147180559945309f; }   // x >= 0 here
+__device__ __forceinline__ float fast_expm1(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f) - 1.0f; }
+__device__ __forceinline__ float fast_abs2(float re, float im) { return __builtin_amdgcn_sqrtf(fmaf(re, re, im * im)); }
+
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }

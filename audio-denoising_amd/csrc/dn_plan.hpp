@@ -17,6 +17,7 @@ struct DspDev {
     const int* mel_len;     // [M]
     const float* mel_w;     // [mel_maxlen][M]  weight of the i-th bin of filter m
     int mel_maxlen;
+    int mel_passlen[2];     // longest band among filters 0..63 and 64..127 (a wavefront takes 64 filters a pass)
     int n_mels;
     const float* pinv_t;    // [M][kPinvStride]  pseudo-inverse of fb^T, transposed, row-padded
     int pinv_stride;

@@ -7,13 +7,17 @@ namespace dn {
 
 constexpr int kStftThreads = 192;
 
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
-    return v;
-}
 
 template <int NFFT> constexpr int stft_smem() { return 4 * NFFT + 8 * 3 * Geo<NFFT>::kTile + 4 * 3 * (Geo<NFFT>::kBins + 7) + 16; }
+
+#ifdef DN_PROBE
+static __device__ unsigned long long g_stft_probe[8];   // diagnostic build: phases of wave 0 of the workgroup of stream 0 (tools/hop_wg_probe.py)
+#define DN_SSTAMP(id) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; \
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); if (b == 0 && tid == 0) g_stft_probe[id] = t_; \
+    __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define DN_SSTAMP(id) do { } while (0)
+#endif
 
 // One workgroup (192 threads = 3 wavefronts = 3 STFT columns) processes frame `b`.  `smem`: stft_smem<NFFT>() bytes of LDS.
 // THREADS > 192: the extra wavefront helps load / normalise the frame and then waits at the end (the three columns are three waves).
@@ -31,6 +35,7 @@ __device__ __forceinline__ void stft_body(char* smem, const DspDev& d, const flo
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
 
+    DN_SSTAMP(0);
     // ---- P1: load the frame once, find max|x|
     const float4* f4 = reinterpret_cast<const float4*>(frames + b * kNR);
     static_assert(kNR / 4 <= 2 * THREADS && THREADS <= 256, "two float4 per thread cover the frame");
@@ -44,6 +49,7 @@ __device__ __forceinline__ void stft_body(char* smem, const DspDev& d, const flo
     mx = wave_max(mx);
     if (lane == 0) red[w] = mx;
     __syncthreads();
+    DN_SSTAMP(1);
     float pk = fmaxf(red[0], fmaxf(red[1], red[2]));
     if (THREADS > 192) pk = fmaxf(pk, red[3]);
     const bool norm = (flags & DN_PEAK_NORMALIZE) && pk > 1e-6f;     // app3.py:182
@@ -52,8 +58,9 @@ __device__ __forceinline__ void stft_body(char* smem, const DspDev& d, const flo
 
     // ---- P1/P2: x / peak, optional first Hann multiply (app3.py:183,188)
     const float4* w4 = reinterpret_cast<const float4*>(d.window);
+    const float ipk = __builtin_amdgcn_rcpf(pk);
     auto prep = [&](float4 q, int i4) {
-        if (norm) { q.x = q.x / pk; q.y = q.y / pk; q.z = q.z / pk; q.w = q.w / pk; }
+        if (norm) { q.x *= ipk; q.y *= ipk; q.z *= ipk; q.w *= ipk; }
         if (flags & DN_PRE_WINDOW) {
             float4 ww = w4[i4];
             q.x *= ww.x; q.y *= ww.y; q.z *= ww.z; q.w *= ww.w;
@@ -64,6 +71,7 @@ __device__ __forceinline__ void stft_body(char* smem, const DspDev& d, const flo
     if (two) prep(q1, tid + THREADS);
     __syncthreads();
     if (THREADS > 192 && w >= 3) return;          // (no workgroup barrier below this point)
+    DN_SSTAMP(2);
 
     // ---- P4: column w of the centred STFT: padded position p = hop w + n, source i = p - hop reflected
     typename G::Fft::Tw tw;
@@ -81,10 +89,12 @@ __device__ __forceinline__ void stft_body(char* smem, const DspDev& d, const flo
         const v2f ww = reinterpret_cast<const v2f*>(d.window)[m];
         v[t] = mk2(xs[i0] * ww[0], xs[i1] * ww[1]);
     }
+    DN_SSTAMP(3);
     G::Fft::template run<false>(v, tw, tile[w], lane);
     // Hermitian split in pair order: this lane gets bins k = lane + 64 t and NC - k (t < NP); lane 0 also bin NC/2
     v2f lo[kNP], hi[kNP], mid;
     rfft_split_pairs<kNV>(v, wkh, lane, lo, hi, mid);
+    DN_SSTAMP(4);
 
     if (WRITE_SPEC) {
         v2f* srow = reinterpret_cast<v2f*>(spec) + (b * 3 + w) * kBins;
@@ -99,18 +109,20 @@ __device__ __forceinline__ void stft_body(char* smem, const DspDev& d, const flo
         // ---- P5: magnitude -> banded mel filterbank -> log1p; P6: rows are already (B,3,M)
 #pragma unroll
         for (int t = 0; t < kNP; ++t) {
-            magbuf[w][lane + 64 * t] = hypotf(lo[t][0], lo[t][1]);
-            magbuf[w][G::kNC - (lane + 64 * t)] = hypotf(hi[t][0], hi[t][1]);
+            magbuf[w][lane + 64 * t] = fast_abs2(lo[t][0], lo[t][1]);
+            magbuf[w][G::kNC - (lane + 64 * t)] = fast_abs2(hi[t][0], hi[t][1]);
         }
-        if (lane == 0) magbuf[w][G::kNC / 2] = hypotf(mid[0], mid[1]);
+        if (lane == 0) magbuf[w][G::kNC / 2] = fast_abs2(mid[0], mid[1]);
         wave_sync();
+        DN_SSTAMP(5);
         float* mrow = mel + (b * 3 + w) * d.n_mels;
         for (int m = lane; m < d.n_mels; m += 64) {
             const int s = d.mel_start[m], len = d.mel_len[m];
             float acc = 0.0f;
             for (int i = 0; i < len; ++i) acc = fmaf(d.mel_w[i * d.n_mels + m], magbuf[w][s + i], acc);
-            mrow[m] = log1pf(acc);
+            mrow[m] = fast_log1p(acc);
         }
+        DN_SSTAMP(6);
     }
 }
 

@@ -135,6 +135,7 @@ inline void __syncthreads() { dn_emu::ctx.block->wait(); }
 // workgroups run one after another and one thread per workgroup takes the ticket: a plain read-modify-write is enough
 inline unsigned int atomicAdd(unsigned int* p, unsigned int v) { unsigned int o = *p; *p = o + v; return o; }
 #define DN_LDS_BARRIER() __syncthreads()
+#define DN_WAVE_REDUCE_SHFL 1
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
 #define __builtin_amdgcn_wave_barrier() dn_emu::ctx.wave->wait()
 #define __builtin_amdgcn_readfirstlane(x) (x)
@@ -145,6 +146,8 @@ inline float __shfl(float v, int src) { return dn_emu::shfl(v, src); }
 using std::max;
 using std::min;
 inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
+inline float __builtin_amdgcn_exp2f(float x) { return std::exp2(x); }
+inline float __builtin_amdgcn_logf(float x) { return std::log2(x); }
 inline float __builtin_amdgcn_sqrtf(float x) { return std::sqrt(x); }
 inline float __builtin_amdgcn_rsqf(float x) { return 1.0f / std::sqrt(x); }
 

@@ -29,3 +29,13 @@ t = [buf[i] for i in range(7)]
 t0 = min(t[0], t[2])
 print(f"head start {os.environ.get('DN_GL_HEAD_START', 'default')}: Griffin-Lim WG 0: start {t[0] - t0}, end {t[1] - t0};  "
       f"front WG 0: start {t[2] - t0}, stft done {t[5] - t0}, cell done {t[6] - t0}, P1-P10 done {t[3] - t0}, head start done {t[4] - t0 if t[4] > t[2] else '-'}  (ticks)")
+inv = (C.c_uint64 * 8)()
+if dn.lib.lib.dn_probe_read_hop_invmel(inv) == 0:
+    v = [inv[i] for i in range(6)]
+    print(f"    inverse mel of front WG 0: residual -> mel {v[1] - v[0]}, first batch requested {v[2] - v[1]}, matrix loop {v[3] - v[2]}, "
+          f"stores {v[4] - v[3]}, left-over bin {v[5] - v[4]}  (ticks)")
+st = (C.c_uint64 * 8)()
+if dn.lib.lib.dn_probe_read_hop_stft(st) == 0:
+    v = [st[i] for i in range(7)]
+    print(f"    analysis of front WG 0, wave 0: frame load + peak {v[1] - v[0]}, normalise + window -> LDS {v[2] - v[1]}, constants + column {v[3] - v[2]}, "
+          f"fft + split {v[4] - v[3]}, magnitudes {v[5] - v[4]}, mel + log1p {v[6] - v[5]}  (ticks)")
