@@ -460,7 +460,8 @@ int dn_dsp_create(const dn_dsp_cfg* cfg, const float* fb_in, const float* pinv_i
     for (int k = 0; k <= NC / 2; ++k) { tw1024[2 * k] = (float)cos(2.0 * PI * k / N); tw1024[2 * k + 1] = (float)-sin(2.0 * PI * k / N); }
     size_t o_tw512 = d->arena.add(tw512.data(), tw512.size() * 4), o_tw1024 = d->arena.add(tw1024.data(), tw1024.size() * 4);
     size_t o_win = d->arena.add(d->window.data(), N * 4), o_env = d->arena.add(inv_env.data(), N * 4);
-    size_t o_ms = 0, o_ml = 0, o_mw = 0, o_pinv = 0;
+    size_t o_ms = 0, o_ml = 0, o_mw = 0, o_pinv = 0, o_ginv = 0, o_fb2 = 0;
+    bool has_factors = false;
     int maxlen = 0, passlen[2] = {0, 0};
     const int pstride = ((K + 767) / 768) * 768;      // the contraction kernels stream rows in rounds of 192 or 256 bins (zero padded: tail loads stay in bounds)
     if (M > 0) {
@@ -495,6 +496,7 @@ int dn_dsp_create(const dn_dsp_cfg* cfg, const float* fb_in, const float* pinv_i
             for (int i = 0; i < len[mm]; ++i) mw[(size_t)i * M + mm] = d->fb[(size_t)(start[mm] + i) * M + mm];
         // pseudo-inverse of fb^T: fb (fb^T fb)^-1, the minimum-norm least-squares operator (Appendix B.4)
         d->pinv.resize((size_t)K * M);
+        std::vector<float> ginv, fb2;
         if (pinv_in) memcpy(d->pinv.data(), pinv_in, d->pinv.size() * 4);
         else {
             std::vector<double> G((size_t)M * M, 0.0), R((size_t)M * K);
@@ -506,7 +508,43 @@ int dn_dsp_create(const dn_dsp_cfg* cfg, const float* fb_in, const float* pinv_i
                 }
             for (int a = 0; a < M; ++a)
                 for (int k = 0; k < K; ++k) R[(size_t)a * K + k] = d->fb[(size_t)k * M + a];   // fb^T
+            std::vector<double> G2 = G, I((size_t)M * M, 0.0);
+            for (int a = 0; a < M; ++a) I[(size_t)a * M + a] = 1.0;
             if (!chol_solve(G, R, M, K)) { delete d; return fail(DN_ERR_INVALID, "mel filterbank is rank deficient; pass pinv explicitly"); }
+            // the factored form needs at most two filters a bin
+            bool two = chol_solve(G2, I, M, M);
+            std::vector<float> f2((size_t)K * 4, 0.0f);
+            for (int k = 0; k < K && two; ++k) {
+                int n = 0;
+                for (int a = 0; a < M; ++a) {
+                    const float wv = d->fb[(size_t)k * M + a];
+                    if (wv == 0.0f) continue;
+                    if (n == 2) { two = false; break; }
+                    f2[(size_t)k * 4 + n] = wv;
+                    memcpy(&f2[(size_t)k * 4 + 2 + n], &a, 4);
+                    ++n;
+                }
+            }
+            if (two) {   // the diagonals beyond the band must be below fp32 resolution
+                double big = 0.0, out = 0.0;
+                for (int a = 0; a < M; ++a)
+                    for (int c = 0; c < M; ++c) {
+                        const double v = fabs(I[(size_t)a * M + c]);
+                        big = v > big ? v : big;
+                        if (abs(a - c) > dn::kInvBand) out = v > out ? v : out;
+                    }
+                two = out <= 1e-8 * big;
+            }
+            if (two) {
+                const int taps = 2 * dn::kInvBand + 1;
+                ginv.assign((size_t)taps * M, 0.0f);
+                for (int t = 0; t < taps; ++t)
+                    for (int a = 0; a < M; ++a) {
+                        const int c = a - dn::kInvBand + t;
+                        if (c >= 0 && c < M) ginv[(size_t)t * M + a] = (float)I[(size_t)a * M + c];
+                    }
+                fb2 = f2;
+            }
             for (int k = 0; k < K; ++k)
                 for (int a = 0; a < M; ++a) d->pinv[(size_t)k * M + a] = (float)R[(size_t)a * K + k];
         }
@@ -517,6 +555,7 @@ int dn_dsp_create(const dn_dsp_cfg* cfg, const float* fb_in, const float* pinv_i
         o_ml = d->arena.add(len.data(), M * 4);
         o_mw = d->arena.add(mw.data(), mw.size() * 4);
         o_pinv = d->arena.add(pt.data(), pt.size() * 4);
+        if (!ginv.empty()) { o_ginv = d->arena.add(ginv.data(), ginv.size() * 4); o_fb2 = d->arena.add(fb2.data(), fb2.size() * 4); has_factors = true; }
     }
     hipError_t e = d->arena.upload();
     if (e != hipSuccess) { d->arena.release(); delete d; return fail(DN_ERR_HIP, std::string("plan upload: ") + hipGetErrorString(e)); }
@@ -534,6 +573,8 @@ int dn_dsp_create(const dn_dsp_cfg* cfg, const float* fb_in, const float* pinv_i
     v.mel_len = M ? d->arena.ptr<int>(o_ml) : nullptr;
     v.mel_w = M ? d->arena.ptr<float>(o_mw) : nullptr;
     v.pinv_t = M ? d->arena.ptr<float>(o_pinv) : nullptr;
+    v.ginv_band = has_factors ? d->arena.ptr<float>(o_ginv) : nullptr;
+    v.fb2 = has_factors ? d->arena.ptr<float4>(o_fb2) : nullptr;
     *out = d;
     return DN_OK;
 }

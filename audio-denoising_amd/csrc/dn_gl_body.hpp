@@ -4,6 +4,7 @@
 
 #include "dn_internal.hpp"
 #include "dn_wavefft.hpp"
+#include "dn_invmel_body.hpp"
 
 namespace dn {
 
@@ -94,16 +95,42 @@ __device__ __forceinline__ void gl_body(char* smem, const DspDev& d, const float
     static_assert(3 * kBinPad <= 2 * kNR && 3 * 128 <= 2 * kNR, "prologue scratch fits one ping-pong half");
     if (FROM_MEL) {
         const int M = d.n_mels;
+        const bool factored = d.ginv_band != nullptr;
+        float4* mel4 = reinterpret_cast<float4*>(mm);     // factored form: (column 0, 1, 2) per filter, kInvBand zero rows on either side
+        if (factored) {
+            for (int i = tid; i < kInvMel4; i += kGlThreads) mel4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            __syncthreads();
+        }
         for (int i = tid; i < 3 * M; i += kGlThreads) {
             const int c = i / M, m = i - c * M;
             float v = mag[(b * 3 + c) * M + m] - diff[(b * 3 + c) * M + m];
             v = v >= 0.0f ? v : 0.2f * v;              // leaky_relu, app3.py:204
-            mm[c * 128 + m] = fmaxf(fast_expm1(v), 0.0f);  // app3.py:207-208 (as dn_invmel_body.hpp)
+            v = fmaxf(fast_expm1(v), 0.0f);            // app3.py:207-208 (as dn_invmel_body.hpp)
+            if (factored) reinterpret_cast<float*>(mel4 + kInvBand + m)[c] = v;
+            else mm[c * 128 + m] = v;
         }
         __syncthreads();
+        constexpr int kRounds = (kBins + kGlThreads - 1) / kGlThreads;
+        if (factored) {
+            // factored form, in the canonical order of dn_invmel_body.hpp (the FFT tiles are free until the first iteration)
+            float4* yp4 = reinterpret_cast<float4*>(smem);
+            float4* y4 = yp4 + kInvThirds * kMaxMels;
+            static_assert(16 * (kInvThirds + 1) * kMaxMels <= 8 * 3 * kFftTile && 16 * kInvMel4 <= 4 * 2 * kNR, "the fold's scratch fits");
+            InvBandFold<kGlThreads> inv;
+            inv.fetch(d, tid);
+            inv.fold(d, mel4, yp4, y4, tid);
+#pragma unroll
+            for (int r = 0; r < kRounds; ++r) {
+                const int k = tid + kGlThreads * r;
+                if (k < kBins) {
+                    const float4 o = invmel_bin(d.fb2[k], y4);
+                    lmag[0 * kBinPad + k] = o.x; lmag[1 * kBinPad + k] = o.y; lmag[2 * kBinPad + k] = o.z;
+                }
+            }
+            __syncthreads();
+        } else {
         // thread <-> bins tid, tid+192, ..: each pinv element is loaded once and used for all 3 columns (pinv_t rows are
         // zero padded to pinv_stride >= kRounds*192, so the tail loads are in bounds)
-        constexpr int kRounds = (kBins + kGlThreads - 1) / kGlThreads;
         float acc[kRounds][3];
 #pragma unroll
         for (int r = 0; r < kRounds; ++r) acc[r][0] = acc[r][1] = acc[r][2] = 0.0f;
@@ -127,6 +154,7 @@ __device__ __forceinline__ void gl_body(char* smem, const DspDev& d, const float
             }
         }
         __syncthreads();
+        }
     }
 
     typename G::Fft::Tw tw;

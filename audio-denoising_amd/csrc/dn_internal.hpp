@@ -88,6 +88,7 @@ constexpr int kGates = 51;       // 3H
 constexpr int kGauss = 6;        // G
 constexpr int kCellChunk = 3;    // time steps whose encoder/decoder run batched (= columns per hop)
 constexpr int kMaxC = 5;         // compressed bins supported by the cell kernel (51*C gate lanes <= 256; F <= 80)
+constexpr int kInvBand = 16;      // diagonals of (fb^T fb)^-1 kept on either side of the main one (DspDev::ginv_band)
 constexpr int kArenaSlack = 8192; // zero bytes behind every device arena: kernels that move whole rounds of an array read past its end (dn_cell_body.hpp)
 
 void launch_stft(const DspDev& d, const float* frames, float* spec, float* mel, float* peak, int B, uint32_t flags,

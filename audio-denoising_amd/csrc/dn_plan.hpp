@@ -21,6 +21,13 @@ struct DspDev {
     int n_mels;
     const float* pinv_t;    // [M][kPinvStride]  pseudo-inverse of fb^T, transposed, row-padded
     int pinv_stride;
+    // The same operator in factors, pinv = fb G^-1 with G = fb^T fb, when the plan built it itself from a bank with at most two filters a bin
+    // (every triangular bank): lin = fb (G^-1 mel).  G is the Gram matrix of overlapping triangles -- nearly tridiagonal -- and its inverse
+    // decays by ~30x every three diagonals: beyond +-16 every entry is below 1e-8 of the largest one (checked when the plan is built),
+    // i.e. below fp32 rounding of the sum it would enter, and is not stored.  33 diagonals of G^-1 and two weights a bin are 19 KB
+    // instead of the dense matrix's 164 KB (80 mels, 513 bins), and ~100 instructions a thread instead of ~900.  nullptr: dense form only.
+    const float* ginv_band; // [33][M]  ginv_band[t][a] = G^-1[a][a - 16 + t] (0 outside the matrix)
+    const float4* fb2;      // [K]      w0, w1, then the two filter indices as integer bits
 };
 
 // Packed GRUUNet2 weights (data channels only; the position-code channels are folded into

@@ -32,8 +32,8 @@ print(f"head start {os.environ.get('DN_GL_HEAD_START', 'default')}: Griffin-Lim 
 inv = (C.c_uint64 * 8)()
 if dn.lib.lib.dn_probe_read_hop_invmel(inv) == 0:
     v = [inv[i] for i in range(6)]
-    print(f"    inverse mel of front WG 0: residual -> mel {v[1] - v[0]}, first batch requested {v[2] - v[1]}, matrix loop {v[3] - v[2]}, "
-          f"stores {v[4] - v[3]}, left-over bin {v[5] - v[4]}  (ticks)")
+    print(f"    inverse mel of front WG 0 (factored form): requests + residual -> mel {v[1] - v[0]}, banded G^-1 mel {v[2] - v[1]}, "
+          f"fb rows + stores {v[3] - v[2]}  (ticks)")
 st = (C.c_uint64 * 8)()
 if dn.lib.lib.dn_probe_read_hop_stft(st) == 0:
     v = [st[i] for i in range(7)]
