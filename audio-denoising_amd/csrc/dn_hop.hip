@@ -146,7 +146,9 @@ __global__ __launch_bounds__(kHopPipeThreads, NFFT == 1536 ? 2 : 1) void hop_ker
             float* slot = a.slot[s];
             stft_body<NFFT, false, true, kHopPipeThreads>(smem, d, frames_in, nullptr, slot, slot + sl.peak, DN_PEAK_NORMALIZE | DN_PRE_WINDOW, b, tid);   // P1-P6
             const int split = min(a.gl_split, a.n_iter);
-            const bool draw = split > 0 && a.init_in == nullptr;
+            // (measured: n_fft 1536, 13 bins a lane: 106 -> 100 us per batch-256 hop; n_fft 1024, 9 bins a lane: 54.7 -> 55.2 us -- the draw's 12 KB
+            // a stream through HBM cost more than the multiplies it moved off the chain, so only the long transform uses it)
+            const bool draw = NFFT == 1536 && split > 0 && a.init_in == nullptr;
             if (draw && tid >= kHopThreads) {
                 // The fourth wave has no column to transform and would wait here: it draws the random initial phases the head start
                 // below begins with (the same Philox blocks, so the same bits) into the slot.  One block per bin is ~10 rounds of

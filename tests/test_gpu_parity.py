@@ -160,6 +160,34 @@ def test_transform_chain_as_the_app_calls_it(dev, tag):
     _wave_close(y.cpu().numpy(), ref_y)
 
 
+@pytest.mark.parametrize("tag", ["S", "R1"])
+def test_inverse_mel_factored_and_dense_forms_agree(dev, tag):
+    """A plan that builds the pseudo-inverse itself runs the inverse mel in factors (fb, banded (fb^T fb)^-1); a plan handed an explicit
+    pseudo-inverse runs the dense contraction.  Same operator: both against the float64 least-squares oracle and against each other,
+    at batch 256 with ragged tails."""
+    from audio_denoising_amd import transforms as T
+    from audio_denoising_amd.transforms import DspPlan
+    from oracle import dsp_np64, dsp_ref
+    p = _params(tag)
+    fb = dsp_ref.melscale_fbanks(p.n_stft, p.n_mels, p.sample_rate)
+    fac = DspPlan(dev, p.sample_rate, p.n_fft, p.hop, p.n_mels, fb=fb)
+    _, pinv, _ = fac.tables()
+    dense = DspPlan(dev, p.sample_rate, p.n_fft, p.hop, p.n_mels, fb=fb, pinv=pinv)
+    g = torch.Generator().manual_seed(31)
+    for rows in (256 * 3, 7):                                  # 7 rows: the last workgroup of three rows is ragged
+        mel = (torch.rand(rows, p.n_mels, generator=g) * 20).to(dev)
+        outs = []
+        for plan in (fac, dense):
+            lin = torch.empty(rows, p.n_stft, device=dev)
+            plan.lib.check(plan.lib.dn_invmel(plan.handle, mel.data_ptr(), lin.data_ptr(), rows, 1, None))
+            torch.cuda.synchronize()
+            outs.append(lin.cpu().numpy())
+        ref = dsp_np64.inverse_mel_scale(mel.cpu().numpy().reshape(rows, p.n_mels, 1), fb.numpy())[..., 0]
+        scale = max(1.0, float(np.abs(ref).max()))
+        assert np.abs(outs[0] - ref).max() <= 2e-5 * scale and np.abs(outs[1] - ref).max() <= 2e-5 * scale
+        assert np.abs(outs[0] - outs[1]).max() <= 2e-5 * scale
+
+
 def test_inverse_spectrogram_round_trip_and_linearity_at_full_batch(dev):
     """Size-independent properties at BASELINE's batch (256): istft(stft(x)) == x, STFT linearity, Parseval."""
     from audio_denoising_amd import transforms as T

@@ -42,6 +42,24 @@ def test_inverse_mel_lstsq_is_min_norm_pinv(p):
     assert np.abs(a - b).max() <= 2e-4
 
 
+@pytest.mark.parametrize("p", PARAMS, ids=["S", "R1", "R2"])
+def test_inverse_mel_in_factors_is_the_same_operator(p):
+    """What the device's factored inverse mel relies on (dn_plan.hpp: ginv_band / fb2): pinv(fb^T) = fb (fb^T fb)^-1, every bin lies in
+    at most two triangles, and (fb^T fb)^-1 has nothing above fp32 resolution beyond +-16 diagonals -- so fb (band16(G^-1) mel) IS the
+    min-norm least-squares solution the reference's InverseMelScale computes, to fp32 rounding."""
+    fb = dsp_ref.melscale_fbanks(p.n_stft, p.n_mels, p.sample_rate).numpy().astype(np.float64)
+    assert ((fb != 0).sum(1) <= 2).all()
+    ginv = np.linalg.inv(fb.T @ fb)
+    i, j = np.indices(ginv.shape)
+    assert np.abs(ginv[np.abs(i - j) > 16]).max() <= 1e-8 * np.abs(ginv).max()
+    band = np.where(np.abs(i - j) <= 16, ginv, 0.0)
+    g = torch.Generator().manual_seed(12)
+    mel = (torch.rand(6, p.n_mels, 3, generator=g) * 20).numpy().astype(np.float64)
+    ref = dsp_np64.inverse_mel_scale(mel.astype(np.float32), fb.astype(np.float32))          # relu(lstsq), float64 inside
+    fac = np.maximum(np.einsum("km,bmt->bkt", fb, np.einsum("mn,bnt->bmt", band, mel)), 0.0)
+    assert np.abs(fac - ref).max() <= 1e-6 * max(1.0, float(np.abs(ref).max()))
+
+
 @pytest.mark.parametrize("p", [pipeline_ref.PARAMS_S, pipeline_ref.PARAMS_R1], ids=["S", "R1"])
 def test_istft_inverts_stft(p):
     g = torch.Generator().manual_seed(3)
