@@ -462,7 +462,9 @@ int dn_dsp_create(const dn_dsp_cfg* cfg, const float* fb_in, const float* pinv_i
     size_t o_win = d->arena.add(d->window.data(), N * 4), o_env = d->arena.add(inv_env.data(), N * 4);
     size_t o_ms = 0, o_ml = 0, o_mw = 0, o_pinv = 0, o_ginv = 0, o_fb2 = 0;
     bool has_factors = false;
-    int maxlen = 0, passlen[2] = {0, 0};
+    int maxlen = 0, qsteps = 0;
+    unsigned qlast = 0;
+    size_t o_q = 0;
     const int pstride = ((K + 767) / 768) * 768;      // the contraction kernels stream rows in rounds of 192 or 256 bins (zero padded: tail loads stay in bounds)
     if (M > 0) {
         d->fb.resize((size_t)K * M);
@@ -489,7 +491,6 @@ int dn_dsp_create(const dn_dsp_cfg* cfg, const float* fb_in, const float* pinv_i
             start[mm] = hi < 0 ? 0 : lo;
             len[mm] = hi < 0 ? 0 : hi - lo + 1;
             maxlen = len[mm] > maxlen ? len[mm] : maxlen;
-            if (mm < 128) passlen[mm / 64] = len[mm] > passlen[mm / 64] ? len[mm] : passlen[mm / 64];
         }
         std::vector<float> mw((size_t)(maxlen ? maxlen : 1) * M, 0.0f);
         for (int mm = 0; mm < M; ++mm)
@@ -551,6 +552,28 @@ int dn_dsp_create(const dn_dsp_cfg* cfg, const float* fb_in, const float* pinv_i
         std::vector<float> pt((size_t)M * pstride, 0.0f);
         for (int k = 0; k < K; ++k)
             for (int a = 0; a < M; ++a) pt[(size_t)a * pstride + k] = d->pinv[(size_t)k * M + a];
+        {   // packed schedule: groups of 16 filters, four lanes a filter, lane l of step u of a group takes tap 4 u + l % 4
+            std::vector<float> q;
+            for (int g = 0; g < M / 16; ++g) {
+                int gl = 0;
+                for (int f = 0; f < 16; ++f) gl = len[16 * g + f] > gl ? len[16 * g + f] : gl;
+                const int steps = gl ? (gl + 3) / 4 : 1;
+                for (int u = 0; u < steps; ++u)
+                    for (int l = 0; l < 64; ++l) {
+                        const int mm = 16 * g + l / 4, i = 4 * u + l % 4;
+                        const bool tap = i < len[mm];
+                        const int bin = tap ? start[mm] + i : 0;
+                        float bits;
+                        memcpy(&bits, &bin, 4);
+                        q.push_back(tap ? mw[(size_t)i * M + mm] : 0.0f);
+                        q.push_back(bits);
+                    }
+                qsteps += steps;
+                if (qsteps <= 32) qlast |= 1u << (qsteps - 1);
+            }
+            if (qsteps > 32) { qsteps = 0; qlast = 0; }
+            else o_q = d->arena.add(q.data(), q.size() * 4);
+        }
         o_ms = d->arena.add(start.data(), M * 4);
         o_ml = d->arena.add(len.data(), M * 4);
         o_mw = d->arena.add(mw.data(), mw.size() * 4);
@@ -567,7 +590,9 @@ int dn_dsp_create(const dn_dsp_cfg* cfg, const float* fb_in, const float* pinv_i
     v.inv_env = d->arena.ptr<float>(o_env);
     v.n_mels = M;
     v.mel_maxlen = maxlen;
-    v.mel_passlen[0] = passlen[0]; v.mel_passlen[1] = passlen[1];
+    v.mel_q = qsteps ? d->arena.ptr<float2>(o_q) : nullptr;
+    v.mel_qsteps = qsteps;
+    v.mel_qlast = qlast;
     v.pinv_stride = pstride;
     v.mel_start = M ? d->arena.ptr<int>(o_ms) : nullptr;
     v.mel_len = M ? d->arena.ptr<int>(o_ml) : nullptr;

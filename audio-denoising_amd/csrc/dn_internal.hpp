@@ -41,6 +41,11 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
     return v;
 }
+__device__ __forceinline__ float quad_sum(float v) {       // the sum of each aligned group of four lanes, in all four
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    return v;
+}
 #else
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_take(float v) {       // lanes without a source keep their own value
@@ -68,6 +73,11 @@ __device__ __forceinline__ float wave_sum(float v) {
     v += dpp_take0<0x142, 0xa>(v);
     v += dpp_take0<0x143, 0xc>(v);
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float quad_sum(float v) {       // the sum of each aligned group of four lanes, in all four
+    v += dpp_take0<0xB1, 0xf>(v);     // quad_perm [1,0,3,2]
+    v += dpp_take0<0x4E, 0xf>(v);     // quad_perm [2,3,0,1]
+    return v;
 }
 #endif
 

@@ -8,7 +8,8 @@ namespace dn {
 constexpr int kStftThreads = 192;
 
 
-template <int NFFT> constexpr int stft_smem() { return 4 * NFFT + 8 * 3 * Geo<NFFT>::kTile + 4 * 3 * (Geo<NFFT>::kBins + 7) + 16; }
+constexpr int kMelQSteps = 32;     // most steps of the packed mel schedule (DspDev::mel_q)
+template <int NFFT> constexpr int stft_smem() { return 4 * NFFT + 8 * 3 * Geo<NFFT>::kTile + 4 * 3 * (Geo<NFFT>::kBins + 7) + 16 + 4 * 3 * 128; }
 
 #ifdef DN_PROBE
 static __device__ unsigned long long g_stft_probe[8];   // diagnostic build: phases of wave 0 of the workgroup of stream 0 (tools/hop_wg_probe.py)
@@ -31,6 +32,8 @@ __device__ __forceinline__ void stft_body(char* smem, const DspDev& d, const flo
     v2f (*tile)[kFftTile] = reinterpret_cast<v2f (*)[kFftTile]>(smem + 4 * kNR);
     float (*magbuf)[kBins + 7] = reinterpret_cast<float (*)[kBins + 7]>(smem + 4 * kNR + 8 * 3 * kFftTile);
     float* red = reinterpret_cast<float*>(smem + 4 * kNR + 8 * 3 * kFftTile + 4 * 3 * (kBins + 7));
+
+    float (*melsum)[128] = reinterpret_cast<float (*)[128]>(red + 4);
 
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -116,11 +119,37 @@ __device__ __forceinline__ void stft_body(char* smem, const DspDev& d, const flo
         wave_sync();
         DN_SSTAMP(5);
         float* mrow = mel + (b * 3 + w) * d.n_mels;
-        for (int m = lane; m < d.n_mels; m += 64) {
-            const int s = d.mel_start[m], len = d.mel_len[m];
+        const int qsteps = d.mel_qsteps;
+        if (qsteps > 0) {
+            // packed schedule (DspDev::mel_q): four lanes share a filter and split its taps, 16 filters a group; a step is one coalesced
+            // 8-byte load (weight, bin), one LDS read and one FMA -- 19 steps against 56 taps of ~6 instructions with a lane per filter
+            // (80 HTK mels at 16 kHz).  This stage is issue bound: it shares its SIMDs with a Griffin-Lim chain that wins arbitration.
+            float2 q[kMelQSteps];
+#pragma unroll
+            for (int t = 0; t < kMelQSteps; ++t) q[t] = t < qsteps ? d.mel_q[t * 64 + lane] : make_float2(0.0f, 0.0f);
             float acc = 0.0f;
-            for (int i = 0; i < len; ++i) acc = fmaf(d.mel_w[i * d.n_mels + m], magbuf[w][s + i], acc);
-            mrow[m] = fast_log1p(acc);
+            int mbase = lane >> 2;
+#pragma unroll
+            for (int t = 0; t < kMelQSteps; ++t) {
+                if (t < qsteps) {                                                  // wave-uniform
+                    acc = fmaf(q[t].x, magbuf[w][__builtin_bit_cast(int, q[t].y)], acc);
+                    if ((d.mel_qlast >> t) & 1u) {                                 // the group's last step: fold the four lanes of a filter
+                        acc = quad_sum(acc);
+                        if ((lane & 3) == 0) melsum[w][mbase] = acc;
+                        mbase += 16;
+                        acc = 0.0f;
+                    }
+                }
+            }
+            wave_sync();
+            for (int m = lane; m < d.n_mels; m += 64) mrow[m] = fast_log1p(melsum[w][m]);
+        } else {
+            for (int m = lane; m < d.n_mels; m += 64) {
+                const int s = d.mel_start[m], len = d.mel_len[m];
+                float acc = 0.0f;
+                for (int i = 0; i < len; ++i) acc = fmaf(d.mel_w[i * d.n_mels + m], magbuf[w][s + i], acc);
+                mrow[m] = fast_log1p(acc);
+            }
         }
         DN_SSTAMP(6);
     }
