@@ -31,7 +31,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // Wave-wide max / sum, the result in every lane.  On the device: six DPP steps on the VALU (row_shr 1, 2, 4, 8, then the row
 // broadcasts 15 and 31 leave the total in lane 63) -- __shfl_xor compiles to ds_bpermute, an LDS round trip of ~230 cycles a step.
-// The CPU emulation tier (tests/emu) has no DPP and defines DN_WAVE_REDUCE_SHFL.
+// (DN_WAVE_REDUCE_SHFL selects the __shfl_xor form, for a build whose target has no DPP.)
 #ifdef DN_WAVE_REDUCE_SHFL
 __device__ __forceinline__ float wave_max(float v) {
     for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
