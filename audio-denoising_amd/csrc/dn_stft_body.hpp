@@ -47,11 +47,31 @@ __device__ __forceinline__ void stft_body(char* smem, const DspDev& d, const flo
     float4 q1 = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool two = tid < (kNR / 4 - THREADS);
     if (two) q1 = f4[tid + THREADS];
+#ifndef DN_STFT_PREFETCH
+#define DN_STFT_PREFETCH 0
+#endif
+    // (experiment knob DN_STFT_PREFETCH: request window and twiddles here, in front of the first barrier, and let both barriers order LDS only)
+    const float4* w4 = reinterpret_cast<const float4*>(d.window);
+    const bool prewin = (flags & DN_PRE_WINDOW) != 0;
+    float4 wq0 = make_float4(1.f, 1.f, 1.f, 1.f), wq1 = wq0;
+    typename G::Fft::Tw tw;
+    v2f wkh[kNP], wwin[kNV];
+    if (DN_STFT_PREFETCH) {
+        wq0 = prewin && one ? w4[tid] : wq0;
+        wq1 = prewin && two ? w4[tid + THREADS] : wq1;
+        if (w < 3) {
+            G::Fft::load(tw, reinterpret_cast<const v2f*>(d.twc), lane);
+#pragma unroll
+            for (int t = 0; t < kNP; ++t) wkh[t] = cscale(reinterpret_cast<const v2f*>(d.twr)[lane + 64 * t], 0.5f);
+#pragma unroll
+            for (int t = 0; t < kNV; ++t) wwin[t] = reinterpret_cast<const v2f*>(d.window)[lane + 64 * t];
+        }
+    }
     float mx = fmaxf(fmaxf(fabsf(q0.x), fabsf(q0.y)), fmaxf(fabsf(q0.z), fabsf(q0.w)));
     mx = fmaxf(mx, fmaxf(fmaxf(fabsf(q1.x), fabsf(q1.y)), fmaxf(fabsf(q1.z), fabsf(q1.w))));
     mx = wave_max(mx);
     if (lane == 0) red[w] = mx;
-    __syncthreads();
+    if (DN_STFT_PREFETCH) DN_LDS_BARRIER(); else __syncthreads();
     DN_SSTAMP(1);
     float pk = fmaxf(red[0], fmaxf(red[1], red[2]));
     if (THREADS > 192) pk = fmaxf(pk, red[3]);
@@ -60,28 +80,28 @@ __device__ __forceinline__ void stft_body(char* smem, const DspDev& d, const flo
     if (peak_out != nullptr && tid == 0) peak_out[b] = pk;
 
     // ---- P1/P2: x / peak, optional first Hann multiply (app3.py:183,188)
-    const float4* w4 = reinterpret_cast<const float4*>(d.window);
     const float ipk = __builtin_amdgcn_rcpf(pk);
-    auto prep = [&](float4 q, int i4) {
+    auto prep = [&](float4 q, float4 ww, int i4) {
         if (norm) { q.x *= ipk; q.y *= ipk; q.z *= ipk; q.w *= ipk; }
-        if (flags & DN_PRE_WINDOW) {
-            float4 ww = w4[i4];
+        if (prewin) {
+            if (!DN_STFT_PREFETCH) ww = w4[i4];
             q.x *= ww.x; q.y *= ww.y; q.z *= ww.z; q.w *= ww.w;
         }
         reinterpret_cast<float4*>(xs)[i4] = q;
     };
-    if (one) prep(q0, tid);
-    if (two) prep(q1, tid + THREADS);
-    __syncthreads();
+    if (one) prep(q0, wq0, tid);
+    if (two) prep(q1, wq1, tid + THREADS);
+    if (DN_STFT_PREFETCH) DN_LDS_BARRIER(); else __syncthreads();
     if (THREADS > 192 && w >= 3) return;          // (no workgroup barrier below this point)
     DN_SSTAMP(2);
 
     // ---- P4: column w of the centred STFT: padded position p = hop w + n, source i = p - hop reflected
-    typename G::Fft::Tw tw;
-    G::Fft::load(tw, reinterpret_cast<const v2f*>(d.twc), lane);
-    v2f wkh[kNP], v[kNV];
+    v2f v[kNV];
+    if (!DN_STFT_PREFETCH) {
+        G::Fft::load(tw, reinterpret_cast<const v2f*>(d.twc), lane);
 #pragma unroll
-    for (int t = 0; t < kNP; ++t) wkh[t] = cscale(reinterpret_cast<const v2f*>(d.twr)[lane + 64 * t], 0.5f);
+        for (int t = 0; t < kNP; ++t) wkh[t] = cscale(reinterpret_cast<const v2f*>(d.twr)[lane + 64 * t], 0.5f);
+    }
 #pragma unroll
     for (int t = 0; t < kNV; ++t) {
         const int m = lane + 64 * t;
@@ -89,7 +109,7 @@ __device__ __forceinline__ void stft_body(char* smem, const DspDev& d, const flo
         int i0 = w * kHop + n0 - kHop, i1 = i0 + 1;
         i0 = i0 < 0 ? -i0 : (i0 >= kNR ? 2 * kNR - 2 - i0 : i0);
         i1 = i1 < 0 ? -i1 : (i1 >= kNR ? 2 * kNR - 2 - i1 : i1);
-        const v2f ww = reinterpret_cast<const v2f*>(d.window)[m];
+        const v2f ww = DN_STFT_PREFETCH ? wwin[t] : reinterpret_cast<const v2f*>(d.window)[m];
         v[t] = mk2(xs[i0] * ww[0], xs[i1] * ww[1]);
     }
     DN_SSTAMP(3);

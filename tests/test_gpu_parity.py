@@ -246,6 +246,42 @@ def test_process_frame_matches_oracle_golden(dev, tag):
     assert np.abs(out.cpu().numpy()[4:6] - g["out"][4:6]).max() <= 1e-3
 
 
+@pytest.mark.parametrize("n_mels", [16, 48])
+def test_process_frame_at_other_filter_counts_matches_the_oracle(dev, n_mels):
+    """Filter counts the goldens do not cover: 16 mels (bands of up to 142 bins: longer than the packed mel schedule takes, so the
+    analysis falls back to a lane per filter; 1 compressed bin) and 48 (3 compressed bins; schedule).  Both run the model with run-time
+    lengths (no compile-time bin count), the factored inverse mel at a different width, pipelined == unpipelined bit for bit."""
+    from audio_denoising_amd.pipeline import Denoiser, HopPipeline
+    from oracle import dsp_ref, pipeline_ref
+    p = pipeline_ref.Params(16000, 1024, 512, n_mels)
+    C = n_mels // 16
+    dn = Denoiser(_model(dev, C), p.sample_rate, p.n_fft, p.hop, p.n_mels)
+    g = torch.Generator().manual_seed(77 + n_mels)
+    frames = 0.1 * torch.randn(12, p.n_fft, generator=g)
+    init = torch.rand(12, p.n_stft, 3, dtype=torch.complex64, generator=g)
+    out, hx, resid = dn.process_frame(frames.to(dev), None, init_angles=init.to(dev), return_residual=True)
+    fb = dsp_ref.melscale_fbanks(p.n_stft, p.n_mels, p.sample_rate)
+    with torch.no_grad():
+        ref = pipeline_ref.process_frame(_state_dict("dari_tult"), frames, torch.zeros(12, 17, C), p, fb, init_angles=init)
+    assert (resid.cpu() - ref["predicted_diff"]).abs().max().item() <= TOL_RESIDUAL
+    assert (hx.cpu() - ref["hx"]).abs().max().item() <= TOL_RESIDUAL
+    _wave_close(out.cpu().numpy(), ref["out"].numpy())
+    # the pipelined hop (256-thread inverse mel) against the unpipelined one (inverse mel as the Griffin-Lim prologue, 192 threads)
+    fd = frames.to(dev)
+    hs, hp = dn.init_hx(12), dn.init_hx(12)
+    serial = [torch.empty_like(fd) for _ in range(3)]
+    piped = [torch.empty_like(fd) for _ in range(3)]
+    pipe = HopPipeline(dn, 12)
+    for i in range(3):
+        dn.process_frame_(fd, hs, serial[i], seed=5 + i, stream_id0=0)
+        pipe.submit(fd, hp, piped[i], seed=5, stream_id0=0)
+    pipe.flush()
+    torch.cuda.synchronize()
+    assert torch.equal(hs, hp)
+    for a, b in zip(serial, piped):
+        assert torch.equal(a, b)
+
+
 def test_process_frame_full_batch_vs_oracle_sample_and_shard_invariance(dev):
     """BASELINE config 2: batch 256, S params.  A bounded sample of streams is checked against the oracle;
     the whole batch is checked by the shard property (two half-batches with global stream ids == one batch)."""
