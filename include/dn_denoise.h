@@ -138,7 +138,10 @@ typedef struct dn_dsp_cfg {
 
 /* fb [host][K][n_mels]: mel filterbank as MelScale.fb (NULL = HTK triangles computed natively, f_min 0,
  * f_max sr//2, norm None).  pinv [host][K][n_mels]: pseudo-inverse of fb^T used by the inverse-mel GEMM
- * (NULL = computed natively in double precision from fb).  window [host][n_fft] (NULL = periodic Hann). */
+ * (NULL = computed natively in double precision from fb; the plan then also keeps the operator in factors, fb and the
+ * significant diagonals of (fb^T fb)^-1, and the kernels apply those when fb has at most two filters per bin -- the same
+ * min-norm least-squares solution to fp32 rounding; an explicit pinv is always applied as the dense matrix).
+ * window [host][n_fft] (NULL = periodic Hann). */
 int dn_dsp_create(const dn_dsp_cfg* cfg, const float* fb, const float* pinv, const float* window, dn_dsp** out);
 void dn_dsp_destroy(dn_dsp* d);
 /* Copies of the plan's host-side tables, for inspection/tests: fb and pinv are [K][n_mels]. */
