@@ -463,7 +463,7 @@ int dn_dsp_create(const dn_dsp_cfg* cfg, const float* fb_in, const float* pinv_i
     size_t o_ms = 0, o_ml = 0, o_mw = 0, o_pinv = 0, o_ginv = 0, o_fb2 = 0;
     bool has_factors = false;
     int maxlen = 0, qsteps = 0;
-    unsigned qlast = 0;
+    unsigned long long qlast = 0;
     size_t o_q = 0;
     const int pstride = ((K + 767) / 768) * 768;      // the contraction kernels stream rows in rounds of 192 or 256 bins (zero padded: tail loads stay in bounds)
     if (M > 0) {
@@ -569,9 +569,9 @@ int dn_dsp_create(const dn_dsp_cfg* cfg, const float* fb_in, const float* pinv_i
                         q.push_back(bits);
                     }
                 qsteps += steps;
-                if (qsteps <= 32) qlast |= 1u << (qsteps - 1);
+                if (qsteps <= dn::mel_q_steps(N)) qlast |= 1ull << (qsteps - 1);
             }
-            if (qsteps > 32) { qsteps = 0; qlast = 0; }
+            if (qsteps > dn::mel_q_steps(N)) { qsteps = 0; qlast = 0; }
             else o_q = d->arena.add(q.data(), q.size() * 4);
         }
         o_ms = d->arena.add(start.data(), M * 4);

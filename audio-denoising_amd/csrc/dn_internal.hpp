@@ -98,6 +98,9 @@ constexpr int kGates = 51;       // 3H
 constexpr int kGauss = 6;        // G
 constexpr int kCellChunk = 3;    // time steps whose encoder/decoder run batched (= columns per hop)
 constexpr int kMaxC = 5;         // compressed bins supported by the cell kernel (51*C gate lanes <= 256; F <= 80)
+// most steps of the packed mel schedule (DspDev::mel_q) a wavefront unrolls: 19 are needed for 80 mels at 16 kHz / n_fft 1024, 39 for 64 mels at
+// 48 kHz / n_fft 1536 (measured: a 48-step unroll costs the n_fft-1024 hop 1 %, and gives the 1536 one 0.8 %)
+constexpr int mel_q_steps(int n_fft) { return n_fft == 1536 ? 48 : 32; }
 constexpr int kInvBand = 16;      // diagonals of (fb^T fb)^-1 kept on either side of the main one (DspDev::ginv_band)
 constexpr int kArenaSlack = 8192; // zero bytes behind every device arena: kernels that move whole rounds of an array read past its end (dn_cell_body.hpp)
 

@@ -18,11 +18,11 @@ struct DspDev {
     const float* mel_w;     // [mel_maxlen][M]  weight of the i-th bin of filter m
     int mel_maxlen;
     // the same bands as a packed schedule for one wavefront (dn_stft_body.hpp): four lanes share a filter (lane l: filter
-    // 16 g + l / 4 of group g, taps 4 u + l % 4), mel_qsteps <= 32 steps of 64 (weight, bin) pairs in lane order; bit t of
+    // 16 g + l / 4 of group g, taps 4 u + l % 4), mel_qsteps <= mel_q_steps(n_fft) = 32 / 48 steps of 64 (weight, bin) pairs in lane order; bit t of
     // mel_qlast = step t closes its group of 16 filters.  mel_qsteps = 0: bands too long for the schedule, use the plain one.
     const float2* mel_q;    // [mel_qsteps][64]  weight, bin index as integer bits (weight 0, bin 0 where a lane has no tap)
     int mel_qsteps;
-    unsigned mel_qlast;
+    unsigned long long mel_qlast;
     int n_mels;
     const float* pinv_t;    // [M][kPinvStride]  pseudo-inverse of fb^T, transposed, row-padded
     int pinv_stride;

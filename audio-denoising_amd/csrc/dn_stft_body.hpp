@@ -8,7 +8,6 @@ namespace dn {
 constexpr int kStftThreads = 192;
 
 
-constexpr int kMelQSteps = 32;     // most steps of the packed mel schedule (DspDev::mel_q)
 template <int NFFT> constexpr int stft_smem() { return 4 * NFFT + 8 * 3 * Geo<NFFT>::kTile + 4 * 3 * (Geo<NFFT>::kBins + 7) + 16 + 4 * 3 * 128; }
 
 #ifdef DN_PROBE
@@ -144,6 +143,7 @@ __device__ __forceinline__ void stft_body(char* smem, const DspDev& d, const flo
             // packed schedule (DspDev::mel_q): four lanes share a filter and split its taps, 16 filters a group; a step is one coalesced
             // 8-byte load (weight, bin), one LDS read and one FMA -- 19 steps against 56 taps of ~6 instructions with a lane per filter
             // (80 HTK mels at 16 kHz).  This stage is issue bound: it shares its SIMDs with a Griffin-Lim chain that wins arbitration.
+            constexpr int kMelQSteps = mel_q_steps(NFFT);
             float2 q[kMelQSteps];
 #pragma unroll
             for (int t = 0; t < kMelQSteps; ++t) q[t] = t < qsteps ? d.mel_q[t * 64 + lane] : make_float2(0.0f, 0.0f);
@@ -153,7 +153,7 @@ __device__ __forceinline__ void stft_body(char* smem, const DspDev& d, const flo
             for (int t = 0; t < kMelQSteps; ++t) {
                 if (t < qsteps) {                                                  // wave-uniform
                     acc = fmaf(q[t].x, magbuf[w][__builtin_bit_cast(int, q[t].y)], acc);
-                    if ((d.mel_qlast >> t) & 1u) {                                 // the group's last step: fold the four lanes of a filter
+                    if ((d.mel_qlast >> t) & 1ull) {                                 // the group's last step: fold the four lanes of a filter
                         acc = quad_sum(acc);
                         if ((lane & 3) == 0) melsum[w][mbase] = acc;
                         mbase += 16;
