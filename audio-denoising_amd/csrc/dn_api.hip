@@ -139,12 +139,12 @@ struct dn_pipe {
     int B = 0, C = 0;
     bool bf16 = false;                        // DN_CONV_BF16: bf16 MFMA conv tiles in the front half
     dn::PipeCtl* ctl = nullptr;               // device-resident hop counter / pending flag (what makes a captured launch replayable)
-    float* scratch[2] = {nullptr, nullptr};   // per slot: mel [B][3][M], residual [B][3][M], peak [B], meta [B][8], lin [B][3][K]
+    float* scratch[2] = {nullptr, nullptr};   // per slot: mel [B][3][M], residual [B][3][M], peak [B], meta [B][kSlotMeta], lin [B][3][K]
     float2* scratch_init[2] = {nullptr, nullptr};   // per slot: the frame's initial phases (allocated on first parity-mode use)
     float2* gl_state[2] = {nullptr, nullptr};       // per slot: a Griffin-Lim chain parked by the head start ([B][3][2 NV + 2][64] complex)
     int gl_split = 0;                               // iterations of head start (0 = none)
     BiasSet* bs = nullptr;
-    float* last_out = nullptr;                // frame mode: where the pending hop's frames go
+    bool submitted = false;                   // frame mode: a hop may be pending (its destination travels in the slot, not here)
     // streaming mode: per-stream state owned by the pipe
     float* ring = nullptr;                    // [B][n_fft] last n_fft input samples
     float* ola = nullptr;                     // [B][n_fft] output overlap-add line
@@ -549,19 +549,19 @@ int dn_dsp_create(const dn_dsp_cfg* cfg, const float* fb_in, const float* pinv_i
             for (int k = 0; k < K; ++k)
                 for (int a = 0; a < M; ++a) d->pinv[(size_t)k * M + a] = (float)R[(size_t)a * K + k];
         }
-        std::vector<float> pt((size_t)M * pstride, 0.0f);
+        std::vector<float> pt((size_t)((M + 15) / 16 * 16) * pstride, 0.0f);      // zero rows up to a multiple of 16: the dense loop walks 16 filters a round
         for (int k = 0; k < K; ++k)
             for (int a = 0; a < M; ++a) pt[(size_t)a * pstride + k] = d->pinv[(size_t)k * M + a];
         {   // packed schedule: groups of 16 filters, four lanes a filter, lane l of step u of a group takes tap 4 u + l % 4
             std::vector<float> q;
-            for (int g = 0; g < M / 16; ++g) {
+            for (int g = 0; g < (M + 15) / 16; ++g) {       // the last group may be partial: lanes of filters that do not exist carry zero weights
                 int gl = 0;
-                for (int f = 0; f < 16; ++f) gl = len[16 * g + f] > gl ? len[16 * g + f] : gl;
+                for (int f = 0; f < 16 && 16 * g + f < M; ++f) gl = len[16 * g + f] > gl ? len[16 * g + f] : gl;
                 const int steps = gl ? (gl + 3) / 4 : 1;
                 for (int u = 0; u < steps; ++u)
                     for (int l = 0; l < 64; ++l) {
                         const int mm = 16 * g + l / 4, i = 4 * u + l % 4;
-                        const bool tap = i < len[mm];
+                        const bool tap = mm < M && i < len[mm];
                         const int bin = tap ? start[mm] + i : 0;
                         float bits;
                         memcpy(&bits, &bin, 4);
@@ -795,7 +795,7 @@ int dn_stream_step(const dn_model* m, const dn_dsp* d, const float* hop_in, floa
 
 // ------------------------------------------------------------------ software-pipelined hops
 static size_t slot_floats(const dn_dsp* d, int32_t B) {
-    return (size_t)B * (6 * (size_t)d->cfg.n_mels + 1 + 8 + 3 * ((size_t)d->cfg.n_fft / 2 + 1));
+    return (size_t)B * (6 * (size_t)d->cfg.n_mels + 1 + dn::kSlotMeta + 3 * ((size_t)d->cfg.n_fft / 2 + 1));
 }
 
 int dn_pipe_create(const dn_model* m, const dn_dsp* d, int32_t B, uint32_t flags, dn_pipe** out) {
@@ -820,8 +820,7 @@ int dn_pipe_create(const dn_model* m, const dn_dsp* d, int32_t B, uint32_t flags
         // the pending hop's chain does not -- measured best at 8 iterations for n_fft 1024 (65.0 -> 56.0 us per batch-256 hop) and 10 for
         // n_fft 1536 (131 -> 103 us); with more streams than CUs every workgroup is busy throughout and it only adds traffic.
         // (The optimum moves up whenever the front half gets shorter: re-run tools/head_start_sweep.sh after changing either half.)
-        const char* hs = getenv("DN_GL_HEAD_START");          // (experiments: tools/head_start_sweep.sh)
-        const int it = hs ? atoi(hs) : (B <= 256 ? (d->cfg.n_fft == 1536 ? 10 : 8) : 0);
+        const int it = B <= 256 ? (d->cfg.n_fft == 1536 ? 10 : 8) : 0;       // (experiments: dn_pipe_set_head_start, tools/head_start_sweep.sh)
         if (it > 0) { rc = dn_pipe_set_head_start(p, it); if (rc != DN_OK) { dn_pipe_destroy(p); return rc; } }
     }
     *out = p;
@@ -851,7 +850,7 @@ int dn_pipe_set_head_start(dn_pipe* p, int32_t iterations) {
         const size_t bytes = (size_t)p->B * 3 * (2 * nv + 2) * 64 * sizeof(float2);
         for (int i = 0; i < 2; ++i) DN_HIP(hipMalloc(reinterpret_cast<void**>(&p->gl_state[i]), bytes));
     }
-    if (iterations > 0) {      // the head start reads its frame's initial phases from the slot (the front workgroup's spare wave draws them)
+    if (iterations > 0 && p->d->cfg.n_fft == 1536) {      // n_fft 1536: the front workgroup's spare wave draws the head start's initial phases into the slot
         int rc = dn_pipe_reserve_parity(p);
         if (rc != DN_OK) return rc;
     }
@@ -983,22 +982,22 @@ int dn_pipe_submit(dn_pipe* p, const float* frames, float* hx, float* out, const
     int rc = fill_hop_args(p, a, init_angles, seed, stream_id0, n_iter, momentum);
     if (rc != DN_OK) return rc;
     a.front_B = p->B; a.frames = frames; a.hx = hx;
-    a.gl_out = p->last_out ? p->last_out : out;      // back half: the hop submitted before this one (none pending on the first launch)
+    a.gl_out = out;                  // THIS hop's destination: its front workgroups leave it in the slot for the Griffin-Lim workgroups of the next launch
     dn::launch_hop(p->d->view, p->bs->view, a, p->bf16, as_stream(stream));
     rc = check_launch("hop_kernel");
     if (rc != DN_OK) return rc;
-    p->last_out = out;               // this hop's Griffin-Lim runs in the next launch
+    p->submitted = true;
     return DN_OK;
 }
 
 int dn_pipe_flush(dn_pipe* p, int32_t n_iter, float momentum, void* stream) {
     if (!p) return fail(DN_ERR_INVALID, "dn_pipe_flush: null pipe");
     if (p->ring) return fail(DN_ERR_INVALID, "dn_pipe_flush: this is a streaming pipe (use dn_pipe_stream_flush)");
-    if (!p->last_out) return DN_OK;  // nothing was ever submitted
+    if (!p->submitted) return DN_OK; // nothing was ever submitted
     dn::HopArgs a{};
     int rc = fill_hop_args(p, a, nullptr, 0, 0, n_iter, momentum);
     if (rc != DN_OK) return rc;
-    a.front_B = 0; a.gl_out = p->last_out;
+    a.front_B = 0;
     dn::launch_hop(p->d->view, p->bs->view, a, p->bf16, as_stream(stream));
     return check_launch("hop_kernel(flush)");
 }

@@ -278,7 +278,7 @@ __device__ __forceinline__ void gl_body(char* smem, const DspDev& d, const float
         DN_STAMP(3);
         __syncthreads();
         DN_STAMP(4);
-        if (it == n_iter) {
+        if (it >= n_iter) {          // (>=: a chain resumed past its end still terminates)
             // final istft: divide by the window envelope, trim, scale (app3.py:217 `* peak`)
             const float sc = scale != nullptr ? scale[b] : 1.0f;
             if (!STREAM) {

@@ -67,11 +67,14 @@ __device__ __forceinline__ void ring_shift(float* ring, const void* hop_in, int 
     __syncthreads();
 }
 
-// offsets (in floats) of the parts of a scratch slot
+// offsets (in floats) of the parts of a scratch slot.  meta: kSlotMeta u32 per stream, written by the frame's front workgroup and read by its
+// Griffin-Lim workgroup in the next launch -- everything the pending hop is finished with is the FRAME's own, not the next call's:
+//   [0] has injected phases  [1,2] Griffin-Lim seed  [3,4] stream id of stream 0  [5] head-start iterations already run
+//   [6] n_iter  [7] momentum / (1 + momentum) (bits)  [8,9] where the frame goes (frame mode: the `out` of its dn_pipe_submit)
 struct SlotLayout {
     size_t diff, peak, meta, lin;
     __host__ __device__ SlotLayout(int B, int M, int K) {
-        diff = (size_t)B * 3 * M; peak = 2 * diff; meta = peak + B; lin = meta + 8 * (size_t)B; (void)K;
+        diff = (size_t)B * 3 * M; peak = 2 * diff; meta = peak + B; lin = meta + kSlotMeta * (size_t)B; (void)K;
     }
 };
 
@@ -112,17 +115,21 @@ __global__ __launch_bounds__(kHopPipeThreads, NFFT == 1536 ? 2 : 1) void hop_ker
             __builtin_amdgcn_s_setprio(DN_GL_PRIO);
             const int s = (int)((frames - 1) & 1);
             const float* slot = a.slot[s];
-            const uint32_t* meta = reinterpret_cast<const uint32_t*>(slot + sl.meta) + 8 * b;
+            const uint32_t* meta = reinterpret_cast<const uint32_t*>(slot + sl.meta) + kSlotMeta * b;
             const v2f* init = meta[0] ? reinterpret_cast<const v2f*>(a.slot_init[s]) : nullptr;
             const uint64_t seed = (uint64_t)meta[1] | ((uint64_t)meta[2] << 32);
             const uint64_t sid0 = (uint64_t)meta[3] | ((uint64_t)meta[4] << 32);
             const int it0 = (int)meta[5];          // iterations the frame's front workgroup already ran (head start)
+            // the frame's own n_iter / momentum (those of its submit, not of this call: it0 <= n_iter by construction) and destination
+            const int n_iter = (int)meta[6];
+            const float mom = __builtin_bit_cast(float, meta[7]);
             v2f* st = reinterpret_cast<v2f*>(a.gl_state[s]);
-            if (!STREAM)
-                gl_body<NFFT, false, false>(smem, d, slot + sl.lin, nullptr, init, seed, sid0, slot + sl.peak, a.gl_out, a.n_iter, a.mom, b, tid,
+            if (!STREAM) {
+                float* gl_out = reinterpret_cast<float*>((uint64_t)meta[8] | ((uint64_t)meta[9] << 32));
+                gl_body<NFFT, false, false>(smem, d, slot + sl.lin, nullptr, init, seed, sid0, slot + sl.peak, gl_out, n_iter, mom, b, tid,
                                             nullptr, nullptr, 0, it0, -1, st);
-            else
-                gl_body<NFFT, false, true>(smem, d, slot + sl.lin, nullptr, init, seed, sid0, slot + sl.peak, nullptr, a.n_iter, a.mom, b, tid,
+            } else
+                gl_body<NFFT, false, true>(smem, d, slot + sl.lin, nullptr, init, seed, sid0, slot + sl.peak, nullptr, n_iter, mom, b, tid,
                                            a.ola, a.hop_out, a.out_s16, it0, -1, st);
             __builtin_amdgcn_s_setprio(0);
             DN_HSTAMP(1);
@@ -169,7 +176,7 @@ __global__ __launch_bounds__(kHopPipeThreads, NFFT == 1536 ? 2 : 1) void hop_ker
             // what this frame's Griffin-Lim (next launch) needs besides the magnitudes: its seed, its stream ids and, in parity mode, its phases
             DN_HSTAMP(3);                          // front half (P1-P10) done
             if (tid == 0) {
-                uint32_t* meta = reinterpret_cast<uint32_t*>(slot + sl.meta) + 8 * b;
+                uint32_t* meta = reinterpret_cast<uint32_t*>(slot + sl.meta) + kSlotMeta * b;
                 const uint64_t seed = a.seed + frames;
                 meta[0] = a.init_in != nullptr ? 1u : 0u;
                 meta[1] = (uint32_t)seed;
@@ -177,6 +184,11 @@ __global__ __launch_bounds__(kHopPipeThreads, NFFT == 1536 ? 2 : 1) void hop_ker
                 meta[3] = (uint32_t)a.sid0;
                 meta[4] = (uint32_t)(a.sid0 >> 32);
                 meta[5] = (uint32_t)split;
+                meta[6] = (uint32_t)a.n_iter;
+                meta[7] = __builtin_bit_cast(uint32_t, a.mom);
+                const uint64_t dst = reinterpret_cast<uint64_t>(a.gl_out);
+                meta[8] = (uint32_t)dst;
+                meta[9] = (uint32_t)(dst >> 32);
             }
             if (a.init_in != nullptr) {
                 const float2* src = reinterpret_cast<const float2*>(a.init_in) + b * 3 * kBins;

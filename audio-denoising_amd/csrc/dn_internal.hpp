@@ -102,6 +102,7 @@ constexpr int kMaxC = 5;         // compressed bins supported by the cell kernel
 // 48 kHz / n_fft 1536 (measured: a 48-step unroll costs the n_fft-1024 hop 1 %, and gives the 1536 one 0.8 %)
 constexpr int mel_q_steps(int n_fft) { return n_fft == 1536 ? 48 : 32; }
 constexpr int kInvBand = 16;      // diagonals of (fb^T fb)^-1 kept on either side of the main one (DspDev::ginv_band)
+constexpr int kSlotMeta = 16;     // u32 of per-stream hand-over data in a pipe's scratch slot (dn_hop.hip: SlotLayout)
 constexpr int kArenaSlack = 8192; // zero bytes behind every device arena: kernels that move whole rounds of an array read past its end (dn_cell_body.hpp)
 
 void launch_stft(const DspDev& d, const float* frames, float* spec, float* mel, float* peak, int B, uint32_t flags,
@@ -127,14 +128,15 @@ struct PipeCtl {
 // Arguments of the software-pipelined hop launch (dn_hop.hip).
 struct HopArgs {
     PipeCtl* ctl;
-    // scratch slots, each: mel [B][3][M] | residual [B][3][M] | peak [B] | meta [B][8] (u32: has_init, seed lo/hi, stream_id0 lo/hi, -) | lin [B][3][K]
+    // scratch slots, each: mel [B][3][M] | residual [B][3][M] | peak [B] | meta [B][kSlotMeta] (u32, see SlotLayout) | lin [B][3][K]
     float* slot[2];
     float2* slot_init[2];    // [B][3][K] complex initial phases of the slot's frame (parity mode), or null
     // front half: this hop's analysis + model + inverse mel, written to slot frames & 1
     const float* frames; float* hx;
     const float* init_in;    // this hop's initial phases [B][3][K] complex (copied into the slot), or null = device RNG
     uint64_t seed, sid0;     // the frame's Griffin-Lim draws from (seed + frame index, sid0 + stream)
-    // back half: the pending hop's Griffin-Lim, read from slot (frames - 1) & 1
+    // back half: the pending hop's Griffin-Lim, read from slot (frames - 1) & 1 -- its n_iter, momentum and destination are the ones the
+    // frame's front workgroup left in the slot (these three describe THIS hop's frame)
     float* gl_out;
     int n_iter; float mom;
     // head start: the front workgroup, done with P1-P10 long before the launch ends, runs the first `gl_split` Griffin-Lim iterations of

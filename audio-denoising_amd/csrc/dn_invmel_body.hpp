@@ -73,7 +73,7 @@ __device__ __forceinline__ float4 invmel_bin(const float4& f, const float4* y4) 
     return make_float4(fmaxf(fmaf(f.y, v.x, f.x * u.x), 0.0f), fmaxf(fmaf(f.y, v.y, f.x * u.y), 0.0f), fmaxf(fmaf(f.y, v.z, f.x * u.z), 0.0f), 0.0f);
 }
 
-static_assert(16 % (2 * DN_INVMEL_UNROLL) == 0, "n_mels is a multiple of 16");
+static_assert(16 % (2 * DN_INVMEL_UNROLL) == 0, "the dense loop's round divides the 16 filters the plan pads to");
 
 #ifdef DN_PROBE
 static __device__ unsigned long long g_inv_probe[8];   // diagnostic build: phases of workgroup r0 == 0 (tools/hop_wg_probe.py)
@@ -122,6 +122,10 @@ __device__ __forceinline__ void invmel_body(char* smem, const DspDev& d, const f
         }
         if (factored) reinterpret_cast<float*>(mel4 + kInvBand + m)[r] = v;
         else mm[r][m] = v;
+    }
+    if (!factored) {          // the dense loop walks 16 filters a round: zero magnitudes for the rows the plan padded (n_mels % 16 != 0)
+        const int Mp = (M + 15) & ~15;
+        for (int i = tid; i < kInvRows * (Mp - M); i += THREADS) mm[i / (Mp - M)][M + i % (Mp - M)] = 0.0f;
     }
     __syncthreads();
     DN_ISTAMP(1);
@@ -173,7 +177,7 @@ __device__ __forceinline__ void invmel_body(char* smem, const DspDev& d, const f
             }
         }
     };
-    // (M is a multiple of 16 = 2 kUB: dn_dsp_create)
+    // (the plan pads pinv_t with zero rows to a multiple of 16 = 2 kUB filters; mm is zero there)
     fetch(pv[0], 0);
     DN_ISTAMP(2);
     for (int m0 = 0; m0 < M; m0 += 2 * kUB) {

@@ -11,6 +11,7 @@ per-stream state the reference keeps in ``input_buffer`` / ``output_ola_buffer``
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -170,6 +171,9 @@ class _Pipe:
             self.lib.check(create(self._owner.handle, denoiser.plan.handle, batch, self._flags, C.byref(handle)))
         self.handle = handle
         self._fin = weakref.finalize(self, self.lib.dn_pipe_destroy, handle)
+        hs = os.environ.get("DN_GL_HEAD_START")       # experiment knob of tools/head_start_sweep.sh (the library itself reads no environment)
+        if hs is not None:
+            self.lib.check(self.lib.dn_pipe_set_head_start(handle, int(hs)))
 
     def _bind(self) -> None:
         """Follow the model: weights reloaded / moved / updated since the last hop -> rebind the pipe (one C call)."""

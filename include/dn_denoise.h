@@ -251,14 +251,17 @@ int dn_pipe_set_model(dn_pipe* p, const dn_model* m);
 /* Head start: a front workgroup is done with P1-P10 well before the pending hop's Griffin-Lim chain (same launch) is; with
  * `iterations` > 0 it goes on with the first iterations of ITS frame's chain and parks it in HBM, and the next launch resumes there.
  * Same results bit for bit, no added latency; pays when there is about one stream per CU.  dn_pipe_create turns it on by itself up to
- * 256 streams (4 iterations at n_fft 1024, 7 at 1536).  Call between launches (0 = off). */
+ * 256 streams (8 iterations at n_fft 1024, 10 at 1536: the measured optima).  Call between launches (0 = off). */
 int dn_pipe_set_head_start(dn_pipe* p, int32_t iterations);
 /* Allocates the per-slot buffers for injected initial phases now (otherwise the first submit/push with init_angles does it):
  * call before capturing a parity-mode launch into a hipGraph, where allocation is not allowed. */
 int dn_pipe_reserve_parity(dn_pipe* p);
 int dn_pipe_submit(dn_pipe* p, const float* frames, float* hx, float* out, const float* init_angles, uint64_t seed,
                    uint64_t stream_id0, int32_t n_iter, float momentum, void* stream);
-/* Runs the pending hop's Griffin-Lim (n_iter / momentum as for the submits); a no-op launch when nothing is pending. */
+/* Runs the pending hop's Griffin-Lim; a no-op launch when nothing is pending.  A pending hop is always finished with the n_iter,
+ * momentum and `out` of ITS OWN submit (they travel with the frame in its scratch slot): the n_iter / momentum arguments of a flush
+ * are validated and otherwise unused, a later submit with other values does not change a hop already submitted, and a captured
+ * submit may be replayed between eager submits to other `out` buffers. */
 int dn_pipe_flush(dn_pipe* p, int32_t n_iter, float momentum, void* stream);
 /* Host copy of the control block (pushes, frames, pending; any may be NULL).  Synchronises `stream`. */
 int dn_pipe_get_counters(dn_pipe* p, uint64_t* pushes, uint64_t* frames, int32_t* pending, void* stream);
@@ -270,7 +273,8 @@ int dn_pipe_get_counters(dn_pipe* p, uint64_t* pushes, uint64_t* frames, int32_t
  * The first n_fft/hop - 1 pushes only fill the ring.  Because hops are software-pipelined, the samples the reference
  * would emit while processing frame f (ola[:hop] before frame f is added, app3.py:219-220) come out of the push
  * that follows the one that delivered frame f's last hop -- one hop of extra latency; zeros until then.
- * dn_pipe_stream_flush emits the last pending hop (zeros when none is pending). */
+ * dn_pipe_stream_flush emits the last pending hop (zeros when none is pending); as in frame mode a pending hop is finished with
+ * the n_iter / momentum of the push that delivered it. */
 int dn_pipe_stream_create(const dn_model* m, const dn_dsp* d, int32_t B, uint32_t flags, dn_pipe** out);
 int dn_pipe_stream_push(dn_pipe* p, const void* hop_in, int32_t in_is_s16, void* hop_out, int32_t out_is_s16,
                         const float* init_angles, uint64_t seed, uint64_t stream_id0, int32_t n_iter, float momentum,

@@ -386,3 +386,75 @@ def test_griffinlim_head_start_is_bit_identical(lib, dsp):
         for a, b in zip(res[0][1], res[split][1]):
             assert np.array_equal(a, b)
     lib.dn_model_destroy(m)
+
+
+def test_pending_hop_is_finished_with_its_own_n_iter_momentum_and_destination(lib, dsp):
+    """A hop submitted with n_iter = 32 and a head start of 8 iterations, then flushed with n_iter = 2 (the state the Python front ends
+    reach when Denoiser.n_iter is lowered between submit() and flush()): the pending chain resumes at iteration 8 > 2 -- it must finish
+    with the n_iter / momentum of ITS submit (they travel in the scratch slot) and terminate.  Likewise its destination: a submit to
+    another buffer in between does not redirect it."""
+    g = load_golden("stream_S.npz")
+    B = 2
+    m = make_model(lib, 5)
+    f0 = emu.f32(g["signal"][:B, :P.n_fft])
+    f1 = emu.f32(g["signal"][:B, P.hop:P.hop + P.n_fft])
+    ref, got = [], []
+    for mode in ("same", "changed"):
+        pipe = C.c_void_p()
+        lib.check(lib.dn_pipe_create(m, dsp, B, 0, C.byref(pipe)))
+        lib.check(lib.dn_pipe_set_head_start(pipe, 8))
+        hx = np.zeros((B, 17, 5), np.float32)
+        o0, o1 = np.zeros((B, P.n_fft), np.float32), np.zeros((B, P.n_fft), np.float32)
+        lib.check(lib.dn_pipe_submit(pipe, emu.ptr(f0), emu.ptr(hx), emu.ptr(o0), None, 11, 3, 32, 0.99, None))
+        if mode == "same":
+            lib.check(lib.dn_pipe_submit(pipe, emu.ptr(f1), emu.ptr(hx), emu.ptr(o1), None, 11, 3, 32, 0.99, None))
+            lib.check(lib.dn_pipe_flush(pipe, 32, 0.99, None))
+            ref = [o0.copy(), o1.copy()]
+        else:
+            # second hop submitted with other settings, flushed with yet others: hop 0 keeps (32, 0.99), hop 1 keeps (32, 0.99) of its own submit
+            lib.check(lib.dn_pipe_submit(pipe, emu.ptr(f1), emu.ptr(hx), emu.ptr(o1), None, 11, 3, 32, 0.99, None))
+            lib.check(lib.dn_pipe_flush(pipe, 2, 0.5, None))
+            got = [o0.copy(), o1.copy()]
+        lib.dn_pipe_destroy(pipe)
+    for a, b in zip(ref, got):
+        assert np.array_equal(a, b)
+    # n_iter really is per frame: a hop submitted with n_iter = 3 differs from one with 32 and equals the unpipelined hop with 3
+    pipe = C.c_void_p()
+    lib.check(lib.dn_pipe_create(m, dsp, B, 0, C.byref(pipe)))
+    lib.check(lib.dn_pipe_set_head_start(pipe, 8))          # more head start than the frame has iterations
+    hx = np.zeros((B, 17, 5), np.float32)
+    o0 = np.zeros((B, P.n_fft), np.float32)
+    lib.check(lib.dn_pipe_submit(pipe, emu.ptr(f0), emu.ptr(hx), emu.ptr(o0), None, 11, 3, 3, 0.99, None))
+    lib.check(lib.dn_pipe_flush(pipe, 32, 0.99, None))
+    lib.dn_pipe_destroy(pipe)
+    ws = np.zeros(int(lib.lib.dn_workspace_bytes(dsp, B)), np.uint8)
+    hx2 = np.zeros((B, 17, 5), np.float32)
+    o2 = np.zeros((B, P.n_fft), np.float32)
+    lib.check(lib.dn_process_frame(m, dsp, emu.ptr(f0), emu.ptr(hx2), emu.ptr(o2), None, None, 11, 3, 3, 0.99, emu.ptr(ws), B, 0, None))
+    assert np.array_equal(o0, o2) and not np.array_equal(o0, ref[0])
+    lib.dn_model_destroy(m)
+
+
+def test_mel_stages_at_a_filter_count_that_is_not_a_multiple_of_16(lib):
+    """n_mels = 40 through the public transform entry points (dn_dsp_create accepts 0..128): the packed mel schedule covers the partial last
+    group of filters, and the dense inverse mel (explicit pinv) walks zero-padded rows instead of reading past the matrix."""
+    M = 40
+    fb = dsp_ref.melscale_fbanks(P.n_stft, M, P.sample_rate).numpy()
+    g = torch.Generator().manual_seed(5)
+    frames = (0.1 * torch.randn(2, P.n_fft, generator=g)).numpy()
+    ref_spec = dsp_ref.spectrogram(torch.from_numpy(frames), P.n_fft, P.hop)
+    ref_mel = torch.log1p(torch.matmul(ref_spec.abs().transpose(-1, -2), torch.from_numpy(fb))).numpy()      # (B, 3, M)
+    for pinv in (None, np.linalg.pinv(fb.astype(np.float64).T).astype(np.float32)):
+        h = C.c_void_p()
+        lib.check(lib.dn_dsp_create(C.byref(DspCfg(P.sample_rate, P.n_fft, P.hop, M)), emu.ptr(emu.f32(fb)),
+                                    None if pinv is None else emu.ptr(emu.f32(pinv)), None, C.byref(h)))
+        mel = np.full((2, 3, M), np.nan, np.float32)
+        lib.check(lib.dn_stft_mel_log1p(h, emu.ptr(emu.f32(frames)), emu.ptr(mel), None, 2, 0, None))
+        assert np.abs(mel - ref_mel).max() <= 2e-5 * max(1.0, np.abs(ref_mel).max())
+        mag = np.expm1(ref_mel).astype(np.float32)
+        lin = np.full((2, 3, P.n_stft), np.nan, np.float32)
+        lib.check(lib.dn_invmel(h, emu.ptr(emu.f32(mag)), emu.ptr(lin), 2, 3, None))
+        ref_lin = np.maximum(np.einsum("km,btm->btk", np.linalg.pinv(fb.astype(np.float64).T), mag.astype(np.float64)), 0.0)
+        assert np.isfinite(lin).all()
+        assert np.abs(lin - ref_lin).max() <= 2e-4 * max(1.0, np.abs(ref_lin).max())
+        lib.dn_dsp_destroy(h)
