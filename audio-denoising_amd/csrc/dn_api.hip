@@ -143,6 +143,7 @@ struct dn_pipe {
     float2* scratch_init[2] = {nullptr, nullptr};   // per slot: the frame's initial phases (allocated on first parity-mode use)
     float2* gl_state[2] = {nullptr, nullptr};       // per slot: a Griffin-Lim chain parked by the head start ([B][3][2 NV + 2][64] complex)
     int gl_split = 0;                               // iterations of head start (0 = none)
+    int gl_schedule = DN_GL_AUTO;                   // Griffin-Lim schedule of the back half (dn_pipe_set_gl_schedule)
     BiasSet* bs = nullptr;
     bool submitted = false;                   // frame mode: a hop may be pending (its destination travels in the slot, not here)
     // streaming mode: per-stream state owned by the pipe
@@ -858,6 +859,16 @@ int dn_pipe_set_head_start(dn_pipe* p, int32_t iterations) {
     return DN_OK;
 }
 
+int dn_pipe_set_gl_schedule(dn_pipe* p, int32_t schedule) {
+    if (!p) return fail(DN_ERR_INVALID, "dn_pipe_set_gl_schedule: null pipe");
+    if (schedule != DN_GL_AUTO && schedule != DN_GL_WAVE_PER_COLUMN && schedule != DN_GL_WAVE_PER_STREAM)
+        return fail(DN_ERR_INVALID, "dn_pipe_set_gl_schedule: unknown schedule");
+    if (schedule == DN_GL_WAVE_PER_STREAM && p->d->cfg.n_fft != 1024)
+        return fail(DN_ERR_UNSUPPORTED, "the wavefront-per-stream Griffin-Lim is built for n_fft 1024");
+    p->gl_schedule = schedule;
+    return DN_OK;
+}
+
 int dn_pipe_set_model(dn_pipe* p, const dn_model* m) {
     if (!p || !m) return fail(DN_ERR_INVALID, "dn_pipe_set_model: null argument");
     if (m == p->m) return DN_OK;
@@ -944,6 +955,10 @@ static int fill_hop_args(dn_pipe* p, dn::HopArgs& a, const float* init_angles, u
     a.init_in = init_angles; a.seed = seed; a.sid0 = stream_id0;
     a.n_iter = n_iter; a.mom = momentum / (1.0f + momentum);
     a.B = p->B; a.C = p->C; a.back_B = p->B;
+    // a wavefront per stream (four streams a workgroup) from four streams per CU up; a wavefront per column (the shortest chain) below
+    const bool per_stream = p->d->cfg.n_fft == 1024 &&
+                            (p->gl_schedule == DN_GL_WAVE_PER_STREAM || (p->gl_schedule == DN_GL_AUTO && p->B >= dn::kGlwAutoStreams));
+    a.back_blocks = per_stream ? (p->B + 3) / 4 : p->B;
     a.prime = p->d->cfg.n_fft / p->d->cfg.hop - 1;
     return DN_OK;
 }

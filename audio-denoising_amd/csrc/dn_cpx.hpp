@@ -25,6 +25,13 @@ __device__ __forceinline__ v2f cadd(v2f a, v2f b) { return a + b; }
 __device__ __forceinline__ v2f csub(v2f a, v2f b) { return a - b; }
 __device__ __forceinline__ v2f cscale(v2f a, float s) { return a * s; }
 
+// elementwise product (re*re, im*im) that is ROUNDED: never contracted into a following add (window products that the three-wave
+// Griffin-Lim rounds by storing them to LDS and the one-wave form keeps in registers: both must give the same bits)
+__device__ __forceinline__ v2f cmul_elem(v2f a, v2f b) {
+    v2f d;
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
 // a + (-i) b  =  (a.re + b.im, a.im - b.re)
 __device__ __forceinline__ v2f cadd_mi(v2f a, v2f b) {
     v2f d;

@@ -299,7 +299,7 @@ __device__ __forceinline__ void gl_body(char* smem, const DspDev& d, const float
                 for (int r = 0; r < kR; ++r) {
                     const int n = tid + kGlThreads * r;
                     if (n < kNR) {
-                        orow[n] = nxt[r] + (y1[n] + yo[n]) * d.inv_env[n] * sc;
+                        orow[n] = fmaf((y1[n] + yo[n]) * d.inv_env[n], sc, nxt[r]);     // (the contraction the compiler makes anyway, spelled out: dn_glw_body.hpp must round alike)
                         if (n < kNR / 2) {
                             if (out_s16) {
                                 const float c = fminf(fmaxf(cur[r], -1.0f), 1.0f) * 32767.0f;      // np.clip, * iinfo(int16).max

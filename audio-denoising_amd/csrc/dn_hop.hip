@@ -19,6 +19,7 @@
 //   advances, so one captured launch replays indefinitely under hipGraph (BASELINE config 5).
 #include "dn_cell_body.hpp"
 #include "dn_gl_body.hpp"
+#include "dn_glw_body.hpp"
 #include "dn_invmel_body.hpp"
 #include "dn_stft_body.hpp"
 
@@ -33,7 +34,9 @@ constexpr int kHopPipeThreads = 256;      // workgroup size of the fused launche
 #define DN_HS_PRIO 1
 #endif
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
-template <int NFFT> constexpr int hop_smem() { return cmax(cmax(kCellSmem, gl_smem<NFFT>()), cmax(stft_smem<NFFT>(), kInvSmem)); }
+template <int NFFT> constexpr int hop_smem() {
+    return cmax(cmax(cmax(kCellSmem, gl_smem<NFFT>()), cmax(stft_smem<NFFT>(), kInvSmem)), NFFT == 1024 ? glw_smem<1024>() : 0);
+}
 static_assert(kHopThreads == kGlThreads && kHopThreads == kStftThreads && kHopThreads == kInvThreads, "one block size for all bodies");
 
 // ring <- concat(ring[hop:], hop_in): every thread holds its float4s before anything is overwritten   (app3.py:174,226)
@@ -88,15 +91,17 @@ struct SlotLayout {
 #ifdef DN_PROBE
 // diagnostic build only: when the two kinds of workgroups of one launch start and finish (workgroups 0 and back_B of the last launch)
 static __device__ unsigned long long g_hop_wg_probe[8];
-#define DN_HSTAMP(id) do { if (tid == 0 && (blockIdx.x == 0 || (int)blockIdx.x == a.back_B)) { unsigned long long t_; \
+#define DN_HSTAMP(id) do { if (tid == 0 && (blockIdx.x == 0 || (int)blockIdx.x == a.back_blocks)) { unsigned long long t_; \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); g_hop_wg_probe[id] = t_; } } while (0)
 #else
 #define DN_HSTAMP(id) do { } while (0)
 #endif
 
 // CT: the number of compressed mel bins when the plan has the usual one (80 mels at n_fft 1024, 64 at 1536), 0 = any (run-time lengths in the model)
-template <int NFFT, bool STREAM, bool BF16, int CT>
-__global__ __launch_bounds__(kHopPipeThreads, NFFT == 1536 ? 2 : 1) void hop_kernel(DspDev d, CellDev cd, HopArgs a) {
+// GLW: the pending hop's Griffin-Lim runs one wavefront per stream (dn_glw_body.hpp: four streams a workgroup, back_blocks = ceil(B / 4)) instead
+//      of one wavefront per column (one stream a workgroup): the schedule for several streams per CU.  Capped at two waves per SIMD.
+template <int NFFT, bool STREAM, bool BF16, int CT, bool GLW>
+__global__ __launch_bounds__(kHopPipeThreads, (NFFT == 1536 || GLW) ? 2 : 1) void hop_kernel(DspDev d, CellDev cd, HopArgs a) {
     constexpr int kNR = NFFT, kBins = Geo<NFFT>::kBins;
     __shared__ __attribute__((aligned(16))) char smem[hop_smem<NFFT>()];
     const int tid = threadIdx.x;
@@ -105,7 +110,36 @@ __global__ __launch_bounds__(kHopPipeThreads, NFFT == 1536 ? 2 : 1) void hop_ker
     const unsigned int pending = a.ctl->pending;
     const SlotLayout sl(a.B, d.n_mels, kBins);
     const bool priming = STREAM && pushes < (unsigned long long)a.prime;
-    if ((int)blockIdx.x < a.back_B) {
+    if (GLW && (int)blockIdx.x < a.back_blocks) {
+        if constexpr (GLW) {
+            const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+            const size_t b = (size_t)blockIdx.x * kGlwStreams + wv;
+            if (pending) {
+                glw_fill_tables<NFFT, kHopPipeThreads>(smem, d, tid);
+                __syncthreads();
+            }
+            if (b < (size_t)a.back_B) {          // (a wave without a stream skips to the ticket: wave 0 always has one)
+                if (pending) {
+                    const int s = (int)((frames - 1) & 1);
+                    const float* slot = a.slot[s];
+                    const uint32_t* meta = reinterpret_cast<const uint32_t*>(slot + sl.meta) + kSlotMeta * b;
+                    const v2f* init = meta[0] ? reinterpret_cast<const v2f*>(a.slot_init[s]) : nullptr;
+                    const uint64_t seed = (uint64_t)meta[1] | ((uint64_t)meta[2] << 32);
+                    const uint64_t sid0 = (uint64_t)meta[3] | ((uint64_t)meta[4] << 32);
+                    const int it0 = (int)meta[5], n_iter = (int)meta[6];
+                    const float mom = __builtin_bit_cast(float, meta[7]);
+                    float* gl_out = reinterpret_cast<float*>((uint64_t)meta[8] | ((uint64_t)meta[9] << 32));
+                    glw_body<NFFT, STREAM>(smem, d, slot + sl.lin, init, seed, sid0, slot + sl.peak, STREAM ? nullptr : gl_out, n_iter, mom, b, lane, wv,
+                                           a.ola, a.hop_out, a.out_s16, it0, reinterpret_cast<const v2f*>(a.gl_state[s]));
+                } else if (STREAM) {
+                    for (int n = lane; n < kNR / 2; n += 64) {
+                        if (a.out_s16) static_cast<short*>(a.hop_out)[b * (kNR / 2) + n] = 0;
+                        else static_cast<float*>(a.hop_out)[b * (kNR / 2) + n] = 0.0f;
+                    }
+                }
+            }
+        }
+    } else if ((int)blockIdx.x < a.back_blocks) {
         const size_t b = blockIdx.x;
         if (tid >= kHopThreads) return;         // (before any barrier: a terminated wave no longer counts at s_barrier)
         DN_HSTAMP(0);
@@ -141,7 +175,7 @@ __global__ __launch_bounds__(kHopPipeThreads, NFFT == 1536 ? 2 : 1) void hop_ker
             }
         }
     } else {
-        const size_t b = blockIdx.x - a.back_B;
+        const size_t b = blockIdx.x - a.back_blocks;
         DN_HSTAMP(2);
         const float* frames_in = a.frames;
         if (STREAM) {
@@ -230,27 +264,32 @@ __global__ __launch_bounds__(kHopPipeThreads, NFFT == 1536 ? 2 : 1) void hop_ker
     }
 }
 
-template <int NFFT, bool STREAM>
+template <int NFFT, bool STREAM, bool GLW>
 static void launch_hop_n(const DspDev& d, const CellDev& c, const HopArgs& a, bool bf16, hipStream_t st) {
-    const dim3 grid(a.back_B + a.front_B), block(kHopPipeThreads);
+    const dim3 grid(a.back_blocks + a.front_B), block(kHopPipeThreads);
     constexpr int kUsualC = NFFT == 1536 ? 4 : 5;
     if (a.C == kUsualC) {
-        if (bf16) hipLaunchKernelGGL((hop_kernel<NFFT, STREAM, true, kUsualC>), grid, block, 0, st, d, c, a);
-        else hipLaunchKernelGGL((hop_kernel<NFFT, STREAM, false, kUsualC>), grid, block, 0, st, d, c, a);
+        if (bf16) hipLaunchKernelGGL((hop_kernel<NFFT, STREAM, true, kUsualC, GLW>), grid, block, 0, st, d, c, a);
+        else hipLaunchKernelGGL((hop_kernel<NFFT, STREAM, false, kUsualC, GLW>), grid, block, 0, st, d, c, a);
     } else {
-        if (bf16) hipLaunchKernelGGL((hop_kernel<NFFT, STREAM, true, 0>), grid, block, 0, st, d, c, a);
-        else hipLaunchKernelGGL((hop_kernel<NFFT, STREAM, false, 0>), grid, block, 0, st, d, c, a);
+        if (bf16) hipLaunchKernelGGL((hop_kernel<NFFT, STREAM, true, 0, GLW>), grid, block, 0, st, d, c, a);
+        else hipLaunchKernelGGL((hop_kernel<NFFT, STREAM, false, 0, GLW>), grid, block, 0, st, d, c, a);
     }
 }
 
+// a.back_blocks says which Griffin-Lim schedule the caller laid the grid out for: back_B workgroups (a wavefront per column) or
+// ceil(back_B / 4) (a wavefront per stream, n_fft 1024 only)
 void launch_hop(const DspDev& d, const CellDev& c, const HopArgs& a, bool bf16, hipStream_t st) {
     const bool stream = a.ola != nullptr;
     if (d.n_fft == 1536) {
-        if (stream) launch_hop_n<1536, true>(d, c, a, bf16, st);
-        else launch_hop_n<1536, false>(d, c, a, bf16, st);
+        if (stream) launch_hop_n<1536, true, false>(d, c, a, bf16, st);
+        else launch_hop_n<1536, false, false>(d, c, a, bf16, st);
+    } else if (a.back_blocks != a.back_B) {
+        if (stream) launch_hop_n<1024, true, true>(d, c, a, bf16, st);
+        else launch_hop_n<1024, false, true>(d, c, a, bf16, st);
     } else {
-        if (stream) launch_hop_n<1024, true>(d, c, a, bf16, st);
-        else launch_hop_n<1024, false>(d, c, a, bf16, st);
+        if (stream) launch_hop_n<1024, true, false>(d, c, a, bf16, st);
+        else launch_hop_n<1024, false, false>(d, c, a, bf16, st);
     }
 }
 

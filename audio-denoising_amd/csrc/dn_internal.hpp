@@ -103,6 +103,7 @@ constexpr int kMaxC = 5;         // compressed bins supported by the cell kernel
 constexpr int mel_q_steps(int n_fft) { return n_fft == 1536 ? 48 : 32; }
 constexpr int kInvBand = 16;      // diagonals of (fb^T fb)^-1 kept on either side of the main one (DspDev::ginv_band)
 constexpr int kSlotMeta = 16;     // u32 of per-stream hand-over data in a pipe's scratch slot (dn_hop.hip: SlotLayout)
+constexpr int kGlwAutoStreams = 768;   // DN_GL_AUTO: from this many streams per pipe on (three per CU of an MI355X; measured crossover between 512 and 768) the back half runs a wavefront per stream
 constexpr int kArenaSlack = 8192; // zero bytes behind every device arena: kernels that move whole rounds of an array read past its end (dn_cell_body.hpp)
 
 void launch_stft(const DspDev& d, const float* frames, float* spec, float* mel, float* peak, int B, uint32_t flags,
@@ -143,6 +144,7 @@ struct HopArgs {
     // ITS frame and parks the chain in gl_state[slot]; the back workgroup of the next launch resumes there (0 = no head start)
     int gl_split; float2* gl_state[2];
     int front_B, back_B, B, C;
+    int back_blocks;         // workgroups of the back half: back_B (a wavefront per column) or ceil(back_B / 4) (a wavefront per stream, dn_glw_body.hpp)
     // streaming mode (pipe-owned per-stream state): the front half first shifts `hop_in` into `ring` and uses the ring
     // as its frame (app3.py:178,226); the back half folds its frame into `ola` and emits `hop_out` (app3.py:219-224)
     const void* hop_in; float* ring; int in_s16; int prime;

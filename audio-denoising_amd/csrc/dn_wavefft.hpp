@@ -137,6 +137,49 @@ template <> struct WaveFft<512> {
         for (int t = 1; t < 8; ++t) v[t] = twmul<INV>(v[t], tw.p2[t - 1]);    // pass 2 (Ns = 64): output stays in registers
         dft8<INV>(v);
     }
+
+    // NB independent transforms of one wavefront in lock step (one tile each): every exchange of one transform is in flight while the
+    // butterflies of the others issue -- the wave hides its own LDS round trips (dn_glw_body.hpp: one wavefront per stream).
+    template <bool INV, int NB>
+    static __device__ __forceinline__ void run_n(v2f (&v)[NB][8], const Tw& tw, v2f* const (&tile)[NB], int lane) {
+#pragma unroll
+        for (int c = 0; c < NB; ++c) dft8<INV>(v[c]);
+        wave_sync();
+#pragma unroll
+        for (int c = 0; c < NB; ++c)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) tile[c][pad0(8 * lane + t)] = v[c][t];
+        wave_sync();
+#pragma unroll
+        for (int c = 0; c < NB; ++c)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) v[c][t] = tile[c][pad0(lane + 64 * t)];
+#pragma unroll
+        for (int c = 0; c < NB; ++c) {
+#pragma unroll
+            for (int t = 1; t < 8; ++t) v[c][t] = twmul<INV>(v[c][t], tw.p1[t - 1]);
+            dft8<INV>(v[c]);
+        }
+        wave_sync();
+        {
+            const int base = ((lane >> 3) << 6) + (lane & 7);
+#pragma unroll
+            for (int c = 0; c < NB; ++c)
+#pragma unroll
+                for (int t = 0; t < 8; ++t) tile[c][pad1(base + 8 * t)] = v[c][t];
+        }
+        wave_sync();
+#pragma unroll
+        for (int c = 0; c < NB; ++c)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) v[c][t] = tile[c][pad1(lane + 64 * t)];
+#pragma unroll
+        for (int c = 0; c < NB; ++c) {
+#pragma unroll
+            for (int t = 1; t < 8; ++t) v[c][t] = twmul<INV>(v[c][t], tw.p2[t - 1]);
+            dft8<INV>(v[c]);
+        }
+    }
 };
 
 template <> struct WaveFft<768> {

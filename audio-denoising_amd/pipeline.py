@@ -174,6 +174,18 @@ class _Pipe:
         hs = os.environ.get("DN_GL_HEAD_START")       # experiment knob of tools/head_start_sweep.sh (the library itself reads no environment)
         if hs is not None:
             self.lib.check(self.lib.dn_pipe_set_head_start(handle, int(hs)))
+        sch = os.environ.get("DN_GL_SCHEDULE")         # likewise: 0 auto, 1 a wavefront per column, 2 a wavefront per stream
+        if sch is not None:
+            self.lib.check(self.lib.dn_pipe_set_gl_schedule(handle, int(sch)))
+
+    def set_gl_schedule(self, schedule: int) -> None:
+        """``_lib.DN_GL_AUTO`` / ``DN_GL_WAVE_PER_COLUMN`` / ``DN_GL_WAVE_PER_STREAM`` (dn_pipe_set_gl_schedule): how the pending hop's
+        Griffin-Lim is laid out on the GPU; results are bit-identical, call between hops."""
+        self.lib.check(self.lib.dn_pipe_set_gl_schedule(self.handle, int(schedule)))
+
+    def set_head_start(self, iterations: int) -> None:
+        """dn_pipe_set_head_start: Griffin-Lim iterations a front workgroup runs of its own frame's chain (0 = off)."""
+        self.lib.check(self.lib.dn_pipe_set_head_start(self.handle, int(iterations)))
 
     def _bind(self) -> None:
         """Follow the model: weights reloaded / moved / updated since the last hop -> rebind the pipe (one C call)."""

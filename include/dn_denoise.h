@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define DN_ABI_VERSION 2
+#define DN_ABI_VERSION 3
 
 typedef enum dn_status {
     DN_OK = 0,
@@ -253,6 +253,17 @@ int dn_pipe_set_model(dn_pipe* p, const dn_model* m);
  * Same results bit for bit, no added latency; pays when there is about one stream per CU.  dn_pipe_create turns it on by itself up to
  * 256 streams (8 iterations at n_fft 1024, 10 at 1536: the measured optima).  Call between launches (0 = off). */
 int dn_pipe_set_head_start(dn_pipe* p, int32_t iterations);
+/* How the pending hop's Griffin-Lim is laid out on the GPU (n_fft 1024; results are bit-identical either way):
+ *   DN_GL_WAVE_PER_COLUMN  three wavefronts per stream, one per STFT column: the shortest chain for one stream -- right when there is
+ *                          about one stream per CU (the batch-256 metric);
+ *   DN_GL_WAVE_PER_STREAM  one wavefront per stream, the three columns interleaved inside it, four streams per workgroup: no workgroup
+ *                          barrier, the overlap-add in registers, four times the streams in flight -- right for several streams per CU;
+ *   DN_GL_AUTO (default)   per stream from 768 streams per pipe on (three per CU of an MI355X: the measured crossover), per column below.
+ * Call between launches. */
+#define DN_GL_AUTO 0
+#define DN_GL_WAVE_PER_COLUMN 1
+#define DN_GL_WAVE_PER_STREAM 2
+int dn_pipe_set_gl_schedule(dn_pipe* p, int32_t schedule);
 /* Allocates the per-slot buffers for injected initial phases now (otherwise the first submit/push with init_angles does it):
  * call before capturing a parity-mode launch into a hipGraph, where allocation is not allowed. */
 int dn_pipe_reserve_parity(dn_pipe* p);

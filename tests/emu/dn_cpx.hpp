@@ -27,6 +27,7 @@ inline v2f mk2(float re, float im) { return v2f{re, im}; }
 inline v2f cadd(v2f a, v2f b) { return a + b; }
 inline v2f csub(v2f a, v2f b) { return a - b; }
 inline v2f cscale(v2f a, float s) { return v2f{a[0] * s, a[1] * s}; }
+inline v2f cmul_elem(v2f a, v2f b) { volatile float r0 = a[0] * b[0], r1 = a[1] * b[1]; return v2f{r0, r1}; }
 inline v2f cadd_mi(v2f a, v2f b) { return v2f{a[0] + b[1], a[1] - b[0]}; }
 inline v2f cadd_pi(v2f a, v2f b) { return v2f{a[0] - b[1], a[1] + b[0]}; }
 template <bool INV> inline v2f cadd_rot(v2f a, v2f b) { return INV ? cadd_pi(a, b) : cadd_mi(a, b); }

@@ -458,3 +458,61 @@ def test_mel_stages_at_a_filter_count_that_is_not_a_multiple_of_16(lib):
         assert np.isfinite(lin).all()
         assert np.abs(lin - ref_lin).max() <= 2e-4 * max(1.0, np.abs(ref_lin).max())
         lib.dn_dsp_destroy(h)
+
+
+def _run_pipe(lib, dsp, m, schedule, B, n_hops, g, head_start=0, stream=False, s16=False, init=None, n_iter=6):
+    """n_hops pipelined hops (frame mode or streaming mode) under one Griffin-Lim schedule; returns everything a hop leaves behind"""
+    from audio_denoising_amd._lib import DN_GL_WAVE_PER_STREAM  # noqa: F401
+    pipe = C.c_void_p()
+    create = lib.dn_pipe_stream_create if stream else lib.dn_pipe_create
+    lib.check(create(m, dsp, B, 0, C.byref(pipe)))
+    lib.check(lib.dn_pipe_set_gl_schedule(pipe, schedule))
+    lib.check(lib.dn_pipe_set_head_start(pipe, head_start))
+    outs = []
+    if not stream:
+        hx = np.zeros((B, 17, 5), np.float32)
+        frames = [emu.f32(g["signal"][:B, h * P.hop: h * P.hop + P.n_fft]) for h in range(n_hops)]
+        outs = [np.zeros((B, P.n_fft), np.float32) for _ in range(n_hops)]
+        for h in range(n_hops):
+            lib.check(lib.dn_pipe_submit(pipe, emu.ptr(frames[h]), emu.ptr(hx), emu.ptr(outs[h]), None if init is None else emu.ptr(init[h]), 11, 3, n_iter, 0.99, None))
+        lib.check(lib.dn_pipe_flush(pipe, n_iter, 0.99, None))
+        outs.append(hx)
+    else:
+        dt = np.int16 if s16 else np.float32
+        for h in range(n_hops + 1):
+            x = g["signal"][:B, h * P.hop:(h + 1) * P.hop]
+            hop_in = np.ascontiguousarray(np.clip(x * 32767.0, -32767, 32767).astype(np.int16)) if s16 else emu.f32(x)
+            o = np.zeros((B, P.hop), dt)
+            lib.check(lib.dn_pipe_stream_push(pipe, emu.ptr(hop_in), int(s16), emu.ptr(o), int(s16), None, 11, 3, n_iter, 0.99, None))
+            outs.append(o)
+        o = np.zeros((B, P.hop), dt)
+        lib.check(lib.dn_pipe_stream_flush(pipe, emu.ptr(o), int(s16), n_iter, 0.99, None))
+        outs.append(o)
+        ring, ola, hx = np.zeros((B, P.n_fft), np.float32), np.zeros((B, P.n_fft), np.float32), np.zeros((B, 17, 5), np.float32)
+        lib.check(lib.dn_pipe_stream_get_state(pipe, emu.ptr(ring), emu.ptr(ola), emu.ptr(hx), None))
+        outs += [ring, ola, hx]
+    lib.dn_pipe_destroy(pipe)
+    return outs
+
+
+@pytest.mark.parametrize("case", ["frames", "frames+head_start", "frames+init", "stream", "stream+s16"])
+def test_griffinlim_one_wavefront_per_stream_is_bit_identical_to_one_per_column(lib, dsp, case):
+    """dn_pipe_set_gl_schedule: the wavefront-per-stream Griffin-Lim (four streams a workgroup, the three columns interleaved in one wave,
+    overlap-add in registers) must reproduce the three-wave chain bit for bit -- frames, overlap-add lines, emitted hops, hx.  B = 5: a
+    full workgroup and one with a single live wave; six iterations (the emulator runs a work-item per OS thread; the gpu tier runs 32)."""
+    from audio_denoising_amd._lib import DN_GL_WAVE_PER_COLUMN, DN_GL_WAVE_PER_STREAM
+    sig = load_golden("stream_S.npz")["signal"]
+    g = {"signal": np.concatenate([sig, 0.5 * sig[:1, ::-1]], axis=0)}          # a fifth stream
+    B, n_hops = 5, 2
+    m = make_model(lib, 5)
+    kw = dict(stream=case.startswith("stream"), s16="s16" in case, head_start=4 if "head_start" in case else 0)
+    if "init" in case:
+        rg = np.random.default_rng(7)
+        kw["init"] = [emu.f32(rg.random((B, 3, P.n_stft, 2))) for _ in range(n_hops)]
+    a = _run_pipe(lib, dsp, m, DN_GL_WAVE_PER_COLUMN, B, n_hops, g, **kw)
+    b = _run_pipe(lib, dsp, m, DN_GL_WAVE_PER_STREAM, B, n_hops, g, **kw)
+    lib.dn_model_destroy(m)
+    assert len(a) == len(b)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    assert sum(int(np.abs(x.astype(np.float64)).max() > 0) for x in a) >= 3           # (the comparison is of real output)

@@ -981,3 +981,82 @@ def test_griffinlim_head_start_is_bit_identical_at_batch_256(dev):
         o = [ps.push(hops[i][:8, :p.hop].contiguous()) for i in range(4)] + [ps.flush()]
         sres.append(torch.cat(o, 1))
     assert torch.equal(sres[0], sres[1])
+
+
+@pytest.mark.parametrize("batch", [5, 1027])
+def test_griffinlim_wavefront_per_stream_is_bit_identical_to_per_column(dev, batch):
+    """dn_pipe_set_gl_schedule: one wavefront per stream (the three columns interleaved in one wave, the overlap-add in registers, four
+    streams a workgroup, no workgroup barrier; the default from 1,024 streams on) against one wavefront per column -- the same frames,
+    hx, overlap-add lines and emitted hops bit for bit: frame mode with device-RNG phases, with injected phases, resuming a head start,
+    and the int16 streaming transport.  Batch 5 / 1,027: a workgroup with one live wave; more streams than the machine holds at once."""
+    from audio_denoising_amd import _lib
+    from audio_denoising_amd.pipeline import Denoiser, HopPipeline, PipelinedStream
+    p = _params("S")
+    dn = Denoiser(_model(dev, 5), p.sample_rate, p.n_fft, p.hop, p.n_mels)
+    g = torch.Generator().manual_seed(4000 + batch)
+    hops = [(0.1 * torch.randn(batch, p.n_fft, generator=g)).to(dev) for _ in range(3)]
+    inits = [torch.rand(batch, p.n_stft, 3, dtype=torch.complex64, generator=g).to(dev) for _ in range(3)]
+    for variant in ("rng", "init", "head_start"):
+        res = []
+        for sched in (_lib.DN_GL_WAVE_PER_COLUMN, _lib.DN_GL_WAVE_PER_STREAM, _lib.DN_GL_AUTO):
+            pipe = HopPipeline(dn, batch)
+            pipe.set_gl_schedule(sched)
+            pipe.set_head_start(5 if variant == "head_start" else 0)
+            hx = dn.init_hx(batch)
+            outs = [torch.empty(batch, p.n_fft, device=dev) for _ in hops]
+            for i, f in enumerate(hops):
+                pipe.submit(f, hx, outs[i], seed=21, stream_id0=9, init_angles=inits[i] if variant == "init" else None)
+            pipe.flush()
+            torch.cuda.synchronize()
+            res.append((hx, outs))
+        for hx, outs in res[1:]:
+            assert torch.equal(hx, res[0][0])
+            for a, b in zip(outs, res[0][1]):
+                assert torch.equal(a, b) and torch.isfinite(a).all()
+        assert res[0][1][0].abs().max().item() > 1e-3
+    # streaming transport, int16 in and out
+    sig = (0.3 * torch.randn(batch, 6 * p.hop, generator=g)).clamp(-1, 1)
+    pcm = (sig * 32767.0).to(torch.int16).to(dev)
+    sres = []
+    for sched in (_lib.DN_GL_WAVE_PER_COLUMN, _lib.DN_GL_WAVE_PER_STREAM):
+        ps = PipelinedStream(dn, batch, seed=3, stream_id0=40)
+        ps.set_gl_schedule(sched)
+        o = [ps.push(pcm[:, i * p.hop:(i + 1) * p.hop].contiguous()) for i in range(6)] + [ps.flush(s16=True)]
+        ring, ola, hx, frames = ps.state()
+        torch.cuda.synchronize()
+        sres.append((torch.cat(o, 1), ola, hx))
+    for a, b in zip(sres[0], sres[1]):
+        assert torch.equal(a, b)
+    assert sres[0][0].dtype == torch.int16 and sres[0][0].abs().max().item() > 0
+
+
+def test_wavefront_per_stream_schedule_matches_the_oracle_at_1024_streams(dev):
+    """The saturated regime's own schedule (BASELINE configs[4]: 1,024 streams per GPU) directly against the oracle: two pipelined hops with
+    injected Griffin-Lim phases, a sample of streams spread over the batch (first, last, one per XCD residue), residual and waveform."""
+    from audio_denoising_amd import _lib
+    from audio_denoising_amd.pipeline import Denoiser, HopPipeline
+    from oracle import dsp_ref, pipeline_ref
+    p = pipeline_ref.PARAMS_S
+    B = 1024
+    dn = Denoiser(_model(dev, 5), p.sample_rate, p.n_fft, p.hop, p.n_mels)
+    g = torch.Generator().manual_seed(88)
+    hops = [0.1 * torch.randn(B, p.n_fft, generator=g) for _ in range(2)]
+    inits = [torch.rand(B, p.n_stft, 3, dtype=torch.complex64, generator=g) for _ in range(2)]
+    pipe = HopPipeline(dn, B)
+    pipe.set_gl_schedule(_lib.DN_GL_WAVE_PER_STREAM)
+    hx = dn.init_hx(B)
+    outs = [torch.empty(B, p.n_fft, device=dev) for _ in hops]
+    for i in range(2):
+        pipe.submit(hops[i].to(dev), hx, outs[i], seed=0, init_angles=inits[i].to(dev))
+    pipe.flush()
+    torch.cuda.synchronize()
+    idx = torch.tensor([0, 1, 2, 3, 129, 258, 387, 516, 645, 774, 903, 1020, 1021, 1022, 1023])
+    fb = dsp_ref.melscale_fbanks(p.n_stft, p.n_mels, p.sample_rate)
+    sd = _state_dict("dari_tult")
+    h = torch.zeros(len(idx), 17, 5)
+    with torch.no_grad():
+        for i in range(2):
+            ref = pipeline_ref.process_frame(sd, hops[i][idx], h, p, fb, init_angles=inits[i][idx])
+            h = ref["hx"]
+            _wave_close(outs[i].cpu()[idx].numpy(), ref["out"].numpy())
+    assert (hx.cpu()[idx] - h).abs().max().item() <= TOL_HX_STREAM
