@@ -139,9 +139,12 @@ struct dn_pipe {
     int B = 0, C = 0;
     bool bf16 = false;                        // DN_CONV_BF16: bf16 MFMA conv tiles in the front half
     dn::PipeCtl* ctl = nullptr;               // device-resident hop counter / pending flag (what makes a captured launch replayable)
-    float* scratch[2] = {nullptr, nullptr};   // per slot: mel [B][3][M], residual [B][3][M], peak [B], meta [B][kSlotMeta], lin [B][3][K]
-    float2* scratch_init[2] = {nullptr, nullptr};   // per slot: the frame's initial phases (allocated on first parity-mode use)
-    float2* gl_state[2] = {nullptr, nullptr};       // per slot: a Griffin-Lim chain parked by the head start ([B][3][2 NV + 2][64] complex)
+    // scratch slots, used round robin by consecutive frames: depth + 1 of them (a frame's slot is read by every segment of its chain)
+    int depth = 1, n_slots = 2;                     // hops of one stream in flight (dn_pipe_set_depth)
+    float* scratch = nullptr;                       // [n_slots] x { mel [B][3][M], residual [B][3][M], peak [B], meta [B][kSlotMeta], lin [B][3][K] }
+    float2* scratch_init = nullptr;                 // [n_slots] x the frame's initial phases [B][3][K] complex (allocated on first parity-mode use)
+    float2* gl_state = nullptr;                     // [n_slots] x a parked Griffin-Lim chain ([B][3][2 NV + 2][64] complex: head start, chain segments)
+    size_t slot_floats = 0, init_elems = 0, state_elems = 0;
     int gl_split = 0;                               // iterations of head start (0 = none)
     int gl_schedule = DN_GL_AUTO;                   // Griffin-Lim schedule of the back half (dn_pipe_set_gl_schedule)
     BiasSet* bs = nullptr;
@@ -811,10 +814,13 @@ int dn_pipe_create(const dn_model* m, const dn_dsp* d, int32_t B, uint32_t flags
     p->d->refs.fetch_add(1);
     rc = build_bias(p->m, p->C, &p->bs);
     if (rc != DN_OK) { dn_pipe_destroy(p); return rc; }
-    const size_t slot = (slot_floats(d, B) * sizeof(float) + 255) & ~size_t(255);
+    p->slot_floats = (slot_floats(d, B) + 63) & ~size_t(63);
+    p->init_elems = (size_t)B * 3 * (d->cfg.n_fft / 2 + 1);
+    p->state_elems = (size_t)B * 3 * (2 * ((size_t)d->cfg.n_fft / 128) + 2) * 64;       // n_fft / 128 complex values per lane
+    static_assert(sizeof(dn::PipeCtl) <= 256, "the control block fits its allocation");
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&p->ctl), 256);
     if (e == hipSuccess) e = hipMemset(p->ctl, 0, 256);
-    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipMalloc(reinterpret_cast<void**>(&p->scratch[i]), slot);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&p->scratch), p->n_slots * p->slot_floats * sizeof(float));
     if (e != hipSuccess) { dn_pipe_destroy(p); return fail(DN_ERR_HIP, std::string("dn_pipe_create: ") + hipGetErrorString(e)); }
     {
         // Griffin-Lim head start: with at most one stream per CU (MI355X: 256 CUs) a front workgroup has slack at the end of a launch that
@@ -830,11 +836,9 @@ int dn_pipe_create(const dn_model* m, const dn_dsp* d, int32_t B, uint32_t flags
 
 void dn_pipe_destroy(dn_pipe* p) {
     if (!p) return;
-    for (int i = 0; i < 2; ++i) {
-        if (p->scratch[i]) (void)hipFree(p->scratch[i]);
-        if (p->scratch_init[i]) (void)hipFree(p->scratch_init[i]);
-        if (p->gl_state[i]) (void)hipFree(p->gl_state[i]);
-    }
+    if (p->scratch) (void)hipFree(p->scratch);
+    if (p->scratch_init) (void)hipFree(p->scratch_init);
+    if (p->gl_state) (void)hipFree(p->gl_state);
     if (p->ctl) (void)hipFree(p->ctl);
     if (p->ring) (void)hipFree(p->ring);
     if (p->ola) (void)hipFree(p->ola);
@@ -846,16 +850,42 @@ void dn_pipe_destroy(dn_pipe* p) {
 
 int dn_pipe_set_head_start(dn_pipe* p, int32_t iterations) {
     if (!p || iterations < 0) return fail(DN_ERR_INVALID, "dn_pipe_set_head_start: bad argument");
-    if (iterations > 0 && !p->gl_state[0]) {
-        const size_t nv = (size_t)p->d->cfg.n_fft / 128;       // complex values per lane
-        const size_t bytes = (size_t)p->B * 3 * (2 * nv + 2) * 64 * sizeof(float2);
-        for (int i = 0; i < 2; ++i) DN_HIP(hipMalloc(reinterpret_cast<void**>(&p->gl_state[i]), bytes));
-    }
+    if (iterations > 0 && p->depth > 1) return fail(DN_ERR_INVALID, "dn_pipe_set_head_start: a pipe deeper than one hop cuts the chain into segments itself");
+    if (iterations > 0 && !p->gl_state) DN_HIP(hipMalloc(reinterpret_cast<void**>(&p->gl_state), p->n_slots * p->state_elems * sizeof(float2)));
     if (iterations > 0 && p->d->cfg.n_fft == 1536) {      // n_fft 1536: the front workgroup's spare wave draws the head start's initial phases into the slot
         int rc = dn_pipe_reserve_parity(p);
         if (rc != DN_OK) return rc;
     }
     p->gl_split = iterations;
+    return DN_OK;
+}
+
+int dn_pipe_set_depth(dn_pipe* p, int32_t depth) {
+    if (!p) return fail(DN_ERR_INVALID, "dn_pipe_set_depth: null pipe");
+    if (depth < 1 || depth > DN_PIPE_MAX_DEPTH) return fail(DN_ERR_INVALID, "dn_pipe_set_depth: depth must be in 1.." + std::to_string(DN_PIPE_MAX_DEPTH));
+    if (depth > 1 && p->d->cfg.n_fft != 1024) return fail(DN_ERR_UNSUPPORTED, "pipes deeper than one hop are built for n_fft 1024");
+    if (depth == p->depth) return DN_OK;
+    // nothing may be in flight: the slots are re-laid out
+    dn::PipeCtl h{};
+    DN_HIP(hipDeviceSynchronize());
+    DN_HIP(hipMemcpy(&h, p->ctl, sizeof(h), hipMemcpyDeviceToHost));
+    if (h.pending != 0) return fail(DN_ERR_INVALID, "dn_pipe_set_depth: hops are in flight (flush first)");
+    const int n_slots = depth + 1;
+    float* scratch = nullptr;
+    float2* state = nullptr;
+    DN_HIP(hipMalloc(reinterpret_cast<void**>(&scratch), n_slots * p->slot_floats * sizeof(float)));
+    if (depth > 1) {
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&state), n_slots * p->state_elems * sizeof(float2));
+        if (e != hipSuccess) { (void)hipFree(scratch); return fail(DN_ERR_HIP, std::string("dn_pipe_set_depth: ") + hipGetErrorString(e)); }
+    }
+    (void)hipFree(p->scratch);
+    if (p->gl_state) (void)hipFree(p->gl_state);
+    if (p->scratch_init) (void)hipFree(p->scratch_init);
+    p->scratch = scratch; p->gl_state = state; p->scratch_init = nullptr;
+    p->depth = depth; p->n_slots = n_slots;
+    if (depth > 1) p->gl_split = 0;             // the chain is cut into segments instead
+    h.slot_next = 0;
+    DN_HIP(hipMemcpy(p->ctl, &h, sizeof(h), hipMemcpyHostToDevice));
     return DN_OK;
 }
 
@@ -865,6 +895,8 @@ int dn_pipe_set_gl_schedule(dn_pipe* p, int32_t schedule) {
         return fail(DN_ERR_INVALID, "dn_pipe_set_gl_schedule: unknown schedule");
     if (schedule == DN_GL_WAVE_PER_STREAM && p->d->cfg.n_fft != 1024)
         return fail(DN_ERR_UNSUPPORTED, "the wavefront-per-stream Griffin-Lim is built for n_fft 1024");
+    if (schedule == DN_GL_WAVE_PER_COLUMN && p->depth > 1)
+        return fail(DN_ERR_INVALID, "a pipe deeper than one hop runs a wavefront per stream and chain segment");
     p->gl_schedule = schedule;
     return DN_OK;
 }
@@ -934,9 +966,7 @@ int dn_pipe_get_counters(dn_pipe* p, uint64_t* pushes, uint64_t* frames, int32_t
 // parity mode: a frame's injected phases travel with its scratch slot (so the caller's buffer is free again after the push)
 int dn_pipe_reserve_parity(dn_pipe* p) {
     if (!p) return fail(DN_ERR_INVALID, "dn_pipe_reserve_parity: null pipe");
-    const size_t bytes = (size_t)p->B * 3 * (p->d->cfg.n_fft / 2 + 1) * sizeof(float2);
-    for (int i = 0; i < 2; ++i)
-        if (!p->scratch_init[i]) DN_HIP(hipMalloc(reinterpret_cast<void**>(&p->scratch_init[i]), bytes));
+    if (!p->scratch_init) DN_HIP(hipMalloc(reinterpret_cast<void**>(&p->scratch_init), p->n_slots * p->init_elems * sizeof(float2)));
     return DN_OK;
 }
 
@@ -945,20 +975,26 @@ static int fill_hop_args(dn_pipe* p, dn::HopArgs& a, const float* init_angles, u
                          float momentum) {
     if (n_iter < 0) return fail(DN_ERR_INVALID, "negative n_iter");
     if (!(momentum >= 0.0f && momentum < 1.0f)) return fail(DN_ERR_INVALID, "momentum must be in [0, 1)");
-    if (init_angles && !p->scratch_init[1]) {
+    if (init_angles && !p->scratch_init) {
         int rc = dn_pipe_reserve_parity(p);
         if (rc != DN_OK) return rc;
     }
     a.ctl = p->ctl;
-    for (int i = 0; i < 2; ++i) { a.slot[i] = p->scratch[i]; a.slot_init[i] = p->scratch_init[i]; a.gl_state[i] = p->gl_state[i]; }
+    a.slots = p->scratch; a.slot_stride = p->slot_floats;
+    a.slot_init = p->scratch_init; a.init_stride = p->init_elems;
+    a.gl_state = p->gl_state; a.state_stride = p->state_elems;
+    a.n_slots = p->n_slots;
     a.gl_split = p->gl_split;
     a.init_in = init_angles; a.seed = seed; a.sid0 = stream_id0;
     a.n_iter = n_iter; a.mom = momentum / (1.0f + momentum);
     a.B = p->B; a.C = p->C; a.back_B = p->B;
     // a wavefront per stream (four streams a workgroup) from four streams per CU up; a wavefront per column (the shortest chain) below
-    const bool per_stream = p->d->cfg.n_fft == 1024 &&
-                            (p->gl_schedule == DN_GL_WAVE_PER_STREAM || (p->gl_schedule == DN_GL_AUTO && p->B >= dn::kGlwAutoStreams));
-    a.back_blocks = per_stream ? (p->B + 3) / 4 : p->B;
+    const bool per_stream = p->depth > 1 || (p->d->cfg.n_fft == 1024 && (p->gl_schedule == DN_GL_WAVE_PER_STREAM ||
+                                                                        (p->gl_schedule == DN_GL_AUTO && p->B >= dn::kGlwAutoStreams)));
+    a.glw = per_stream ? 1 : 0;
+    a.depth = p->depth;
+    a.spb = per_stream ? 4 / p->depth : 1;          // a workgroup is four wavefronts: streams x chain segments
+    a.back_blocks = (p->B + a.spb - 1) / a.spb;
     a.prime = p->d->cfg.n_fft / p->d->cfg.hop - 1;
     return DN_OK;
 }
@@ -1013,8 +1049,12 @@ int dn_pipe_flush(dn_pipe* p, int32_t n_iter, float momentum, void* stream) {
     int rc = fill_hop_args(p, a, nullptr, 0, 0, n_iter, momentum);
     if (rc != DN_OK) return rc;
     a.front_B = 0;
-    dn::launch_hop(p->d->view, p->bs->view, a, p->bf16, as_stream(stream));
-    return check_launch("hop_kernel(flush)");
+    for (int i = 0; i < p->depth; ++i) {            // every launch advances each hop in flight by one chain segment
+        dn::launch_hop(p->d->view, p->bs->view, a, p->bf16, as_stream(stream));
+        rc = check_launch("hop_kernel(flush)");
+        if (rc != DN_OK) return rc;
+    }
+    return DN_OK;
 }
 
 }  // extern "C"

@@ -20,6 +20,16 @@ namespace dn {
 
 constexpr int kGlwStreams = 4;        // streams (= wavefronts) per workgroup
 
+#ifdef DN_PROBE
+// diagnostic build only: s_memtime stamps of the four wavefronts of workgroup 0 (tools/glw_probe.py)
+static __device__ unsigned long long g_glw_probe[4][8];
+#define DN_WSTAMP(id) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_glw_probe[threadIdx.x >> 6][id] = t_; \
+    __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define DN_WSTAMP(id) do { } while (0)
+#endif
+
 template <int NFFT> struct GlwLds {
     using G = Geo<NFFT>;
     static constexpr int kCw = 0;                                       // v2f [3][NC]  analysis window x 1/envelope of each column's source samples
@@ -52,12 +62,20 @@ __device__ __forceinline__ void glw_fill_tables(char* smem, const DspDev& d, int
     }
 }
 
-// One wavefront (`lane`, wave `wv` of its workgroup) runs the whole chain of stream `b`.  mag: linear magnitudes [B][3][K].
+// One wavefront (`lane`, wave `wv` of its workgroup) runs iterations [it_begin, it_stop) of the chain of stream `b` -- or, with it_stop < 0, everything
+// from it_begin to the end, and emits the frame.  mag: linear magnitudes [B][3][K].  The chain can be cut between any two iterations without changing
+// a bit (chain segments of a deep pipe).  A segment that stops early parks the chain in `state`; `resume` says where this one starts from:
+//   kGlwFresh    the initial phases (injected or drawn);
+//   kGlwFromX    what gl_body parks (a front workgroup's head start): X = angles * magnitude and the previous rebuilt spectrum of every lane;
+//   kGlwFromSeg  what an earlier segment of this body parked: the rebuilt SIGNAL (n_fft floats -- the spectrum X is one synthesis away from it) and
+//                the previous rebuilt spectrum, 17.5 KB a stream in 16-byte rows instead of gl_body's 27.6 KB in 8-byte rows.  Every launch of a
+//                deep pipe moves this through HBM for every stream and segment boundary, all CUs at once, at the head of the launch.
+constexpr int kGlwFresh = 0, kGlwFromX = 1, kGlwFromSeg = 2;
 template <int NFFT, bool STREAM>
 __device__ __forceinline__ void glw_body(char* smem, const DspDev& d, const float* __restrict__ mag, const v2f* __restrict__ init,
                                          uint64_t seed, uint64_t sid0, const float* __restrict__ scale, float* __restrict__ wave,
                                          int n_iter, float mom, size_t b, int lane, int wv, float* ola, void* hop_out, int out_s16,
-                                         int it_begin, const v2f* __restrict__ state) {
+                                         int it_begin, int it_stop, int resume, v2f* __restrict__ state) {
     using G = Geo<NFFT>;
     using L = GlwLds<NFFT>;
     static_assert(NFFT == 1024, "one wavefront per stream is built for n_fft 1024");
@@ -117,43 +135,125 @@ __device__ __forceinline__ void glw_body(char* smem, const DspDev& d, const floa
         wave_sync();
     };
 
-    {   // ---- prologue: magnitudes, initial phases (injected, drawn, or the chain a head start parked), first synthesis
+    const bool park = it_stop >= 0;
+    const int it_last = park ? it_stop : n_iter;
+    // segment format: per stream 19 rows of 64 lanes -- rows 0..11: float4 (plo pairs, phi pairs of columns 0, 1, 2), rows 12..15: float4 (signal
+    // pairs), then three v2f rows (pmid): 16 x 1 KB + 3 x 512 B
+    constexpr int kSegBytes = 16 * 1024 + 3 * 512;
+    static_assert(kSegBytes <= 8 * 3 * (2 * kNV + 2) * 64, "a parked segment fits the slot gl_body's format needs");
+    char* seg = state != nullptr ? reinterpret_cast<char*>(state) + b * (size_t)(8 * 3 * (2 * kNV + 2) * 64) : nullptr;
+    auto park_segment = [&]() {
+        float4* q = reinterpret_cast<float4*>(seg) + lane;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+#pragma unroll
+            for (int h = 0; h < kNP / 2; ++h) {
+                q[64 * (4 * c + h)] = make_float4(plo[c][2 * h][0], plo[c][2 * h][1], plo[c][2 * h + 1][0], plo[c][2 * h + 1][1]);
+                q[64 * (4 * c + 2 + h)] = make_float4(phi[c][2 * h][0], phi[c][2 * h][1], phi[c][2 * h + 1][0], phi[c][2 * h + 1][1]);
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < kNV / 2; ++h) q[64 * (12 + h)] = make_float4(snew[2 * h][0], snew[2 * h][1], snew[2 * h + 1][0], snew[2 * h + 1][1]);
+        v2f* r = reinterpret_cast<v2f*>(seg + 16 * 1024) + lane;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) r[64 * c] = pmid[c];
+    };
+    {   // ---- prologue: magnitudes, initial phases (injected, drawn, or the chain a head start / an earlier segment parked), first synthesis
+        // (three straight-line variants behind ONE uniform branch each: every load of a variant is in flight before the first is waited for)
         v2f xlo[3][kNP], xhi[3][kNP], xmid[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const size_t row = (b * 3 + c) * kBins;
-            const v2f* st = state != nullptr ? state + ((b * 3 + c) * (2 * kNV + 2)) * 64 + lane : nullptr;
 #pragma unroll
             for (int t = 0; t < kNP; ++t) {
                 const int k = lane + 64 * t, kh = kNC - k;
                 mlo[c][t] = mag != nullptr ? mag[row + k] : 1.0f;
                 mhi[c][t] = mag != nullptr ? mag[row + kh] : 1.0f;
-                if (it_begin > 0) {
+            }
+            mmid[c] = mag != nullptr ? mag[row + kNC / 2] : 1.0f;
+        }
+        if (resume == kGlwFromSeg) {
+            const float4* q = reinterpret_cast<const float4*>(seg) + lane;
+            float4 pq[12], sq[4];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) pq[i] = q[64 * i];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sq[i] = q[64 * (12 + i)];
+            const v2f* r = reinterpret_cast<const v2f*>(seg + 16 * 1024) + lane;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) pmid[c] = r[64 * c];
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int h = 0; h < kNP / 2; ++h) {
+                    plo[c][2 * h] = mk2(pq[4 * c + h].x, pq[4 * c + h].y); plo[c][2 * h + 1] = mk2(pq[4 * c + h].z, pq[4 * c + h].w);
+                    phi[c][2 * h] = mk2(pq[4 * c + 2 + h].x, pq[4 * c + 2 + h].y); phi[c][2 * h + 1] = mk2(pq[4 * c + 2 + h].z, pq[4 * c + 2 + h].w);
+                }
+#pragma unroll
+            for (int h = 0; h < kNV / 2; ++h) { snew[2 * h] = mk2(sq[h].x, sq[h].y); snew[2 * h + 1] = mk2(sq[h].z, sq[h].w); }
+            // the reflected half columns of the analysis read the signal from the wave's LDS line
+#pragma unroll
+            for (int t = 0; t < kNV; ++t) *reinterpret_cast<v2f*>(sl + 2 * (lane + 64 * t)) = snew[t];
+            wave_sync();
+        } else if (resume == kGlwFromX) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const v2f* st = state + ((b * 3 + c) * (2 * kNV + 2)) * 64 + lane;
+#pragma unroll
+                for (int t = 0; t < kNP; ++t) {
                     xlo[c][t] = st[64 * t]; xhi[c][t] = st[64 * (kNP + t)];
                     plo[c][t] = st[64 * (kNV + 1 + t)]; phi[c][t] = st[64 * (kNV + 1 + kNP + t)];
-                } else {
-                    const v2f alo = init != nullptr ? init[row + k] : rand_angle(seed, sid0 + b, c, k);
-                    const v2f ahi = init != nullptr ? init[row + kh] : rand_angle(seed, sid0 + b, c, kh);
-                    xlo[c][t] = alo * mlo[c][t];
-                    xhi[c][t] = ahi * mhi[c][t];
+                }
+                xmid[c] = st[64 * kNV];
+                pmid[c] = st[64 * (2 * kNV + 1)];
+            }
+        } else {
+            if (init != nullptr) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const size_t row = (b * 3 + c) * kBins;
+#pragma unroll
+                    for (int t = 0; t < kNP; ++t) {
+                        xlo[c][t] = init[row + lane + 64 * t];
+                        xhi[c][t] = init[row + kNC - (lane + 64 * t)];
+                    }
+                    xmid[c] = init[row + kNC / 2];
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+#pragma unroll
+                    for (int t = 0; t < kNP; ++t) {
+                        xlo[c][t] = rand_angle(seed, sid0 + b, c, lane + 64 * t);
+                        xhi[c][t] = rand_angle(seed, sid0 + b, c, kNC - (lane + 64 * t));
+                    }
+                    xmid[c] = rand_angle(seed, sid0 + b, c, kNC / 2);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+#pragma unroll
+                for (int t = 0; t < kNP; ++t) {
+                    xlo[c][t] = xlo[c][t] * mlo[c][t];
+                    xhi[c][t] = xhi[c][t] * mhi[c][t];
                     plo[c][t] = mk2(0.0f, 0.0f);
                     phi[c][t] = mk2(0.0f, 0.0f);
                 }
-            }
-            mmid[c] = mag != nullptr ? mag[row + kNC / 2] : 1.0f;
-            if (it_begin > 0) {
-                xmid[c] = st[64 * kNV];
-                pmid[c] = st[64 * (2 * kNV + 1)];
-            } else {
-                const v2f amid = init != nullptr ? init[row + kNC / 2] : rand_angle(seed, sid0 + b, c, kNC / 2);
-                xmid[c] = amid * mmid[c];
+                xmid[c] = xmid[c] * mmid[c];
                 pmid[c] = mk2(0.0f, 0.0f);
             }
         }
-        synthesize(xlo, xhi, xmid);
+        DN_WSTAMP(2);
+        if (resume != kGlwFromSeg) synthesize(xlo, xhi, xmid);
+        DN_WSTAMP(3);
+        if (park && it_begin >= it_last) {        // an empty segment: the chain stays (or, for a new one, is put) where the next segment expects it
+            if (resume != kGlwFromSeg) park_segment();
+            return;
+        }
     }
 
-    for (int it = it_begin; it < n_iter; ++it) {
+    for (int it = it_begin; it < it_last; ++it) {
+        if (it == it_begin + 1) DN_WSTAMP(4);
         // ---- stft of the rebuilt signal (centre, reflect) -> phase update -> istft, side columns as a pair, then the centre column
         v2f xlo[3][kNP], xhi[3][kNP], xmid[3];
         {
@@ -200,7 +300,14 @@ __device__ __forceinline__ void glw_body(char* smem, const DspDev& d, const floa
         }
         synthesize(xlo, xhi, xmid);
     }
+    if (park) {          // hand the chain over (uniform)
+        DN_WSTAMP(5);
+        park_segment();
+        DN_WSTAMP(6);
+        return;
+    }
 
+    DN_WSTAMP(5);
     // ---- final istft: divide by the window envelope, trim, scale (app3.py:217 `* peak`); streaming: fold into the overlap-add line (P12)
     const float sc = scale != nullptr ? scale[b] : 1.0f;
     if (!STREAM) {

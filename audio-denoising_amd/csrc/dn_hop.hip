@@ -97,41 +97,76 @@ static __device__ unsigned long long g_hop_wg_probe[8];
 #define DN_HSTAMP(id) do { } while (0)
 #endif
 
+// slot of the frame that is `back` frames behind the next one (slot_next is the slot the next front half writes)
+__device__ __forceinline__ int slot_behind(unsigned int slot_next, int back, int n_slots) {
+    int s = (int)slot_next - back;
+    while (s < 0) s += n_slots;
+    return s;
+}
+
 // CT: the number of compressed mel bins when the plan has the usual one (80 mels at n_fft 1024, 64 at 1536), 0 = any (run-time lengths in the model)
-// GLW: the pending hop's Griffin-Lim runs one wavefront per stream (dn_glw_body.hpp: four streams a workgroup, back_blocks = ceil(B / 4)) instead
-//      of one wavefront per column (one stream a workgroup): the schedule for several streams per CU.  Capped at two waves per SIMD.
+// GLW: the pending hops' Griffin-Lim runs one wavefront per stream and chain segment (dn_glw_body.hpp) instead of one wavefront per column (one
+//      stream a workgroup, one pending hop).  A workgroup then holds a.spb streams x a.depth chain segments (spb x depth <= 4):
+//        depth 1  four streams a workgroup: the saturated regime (several streams per CU);
+//        depth D  a stream's chain is cut into D segments that run in D consecutive launches, so D hops of the SAME stream are in flight
+//                 (wave j of the workgroup advances frame frames-1-j by its next segment and parks it in HBM, the last segment emits): with
+//                 about one stream per CU this is what fills the CU -- throughput of the saturated regime at batch 256 for D - 1 more
+//                 hops of latency.
+//      Capped at two waves per SIMD.
 template <int NFFT, bool STREAM, bool BF16, int CT, bool GLW>
 __global__ __launch_bounds__(kHopPipeThreads, (NFFT == 1536 || GLW) ? 2 : 1) void hop_kernel(DspDev d, CellDev cd, HopArgs a) {
     constexpr int kNR = NFFT, kBins = Geo<NFFT>::kBins;
     __shared__ __attribute__((aligned(16))) char smem[hop_smem<NFFT>()];
     const int tid = threadIdx.x;
     // control block as the previous launch left it (uniform: scalar loads)
-    const unsigned long long pushes = a.ctl->pushes, frames = a.ctl->frames;
-    const unsigned int pending = a.ctl->pending;
+    const unsigned long long pushes = a.ctl->pushes, frames = a.ctl->frames, launches = a.ctl->launches;
+    const unsigned int pending = a.ctl->pending, slot_next = a.ctl->slot_next;
     const SlotLayout sl(a.B, d.n_mels, kBins);
     const bool priming = STREAM && pushes < (unsigned long long)a.prime;
+    // the oldest frame in flight completes in this launch when this is its last segment (wavefront per column: depth 1, always)
+    const int depth = GLW ? a.depth : 1;
+    const bool completes = pending > 0 && launches - a.ctl->front_launch[(frames - pending) & 7] == (unsigned long long)depth;
     if (GLW && (int)blockIdx.x < a.back_blocks) {
         if constexpr (GLW) {
             const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-            const size_t b = (size_t)blockIdx.x * kGlwStreams + wv;
+            const int sidx = wv / depth, j = wv - sidx * depth;          // stream of the workgroup, frames behind the newest (uniform)
+            const size_t b = (size_t)blockIdx.x * a.spb + sidx;
+            DN_WSTAMP(0);
             if (pending) {
                 glw_fill_tables<NFFT, kHopPipeThreads>(smem, d, tid);
                 __syncthreads();
             }
-            if (b < (size_t)a.back_B) {          // (a wave without a stream skips to the ticket: wave 0 always has one)
-                if (pending) {
-                    const int s = (int)((frames - 1) & 1);
-                    const float* slot = a.slot[s];
+            DN_WSTAMP(1);
+            if (sidx < a.spb && b < (size_t)a.back_B) {          // (a wave without work skips to the ticket: wave 0 always has a stream)
+                if (j < (int)pending) {
+                    const unsigned long long g = frames - 1 - j;                                          // the frame
+                    const int seg = (int)(launches - a.ctl->front_launch[g & 7]) - 1;                     // its next segment: 0 .. depth-1
+                    const int s = slot_behind(slot_next, 1 + j, a.n_slots);
+                    const float* slot = a.slots + (size_t)s * a.slot_stride;
                     const uint32_t* meta = reinterpret_cast<const uint32_t*>(slot + sl.meta) + kSlotMeta * b;
-                    const v2f* init = meta[0] ? reinterpret_cast<const v2f*>(a.slot_init[s]) : nullptr;
+                    const v2f* init = meta[0] ? reinterpret_cast<const v2f*>(a.slot_init + (size_t)s * a.init_stride) : nullptr;
                     const uint64_t seed = (uint64_t)meta[1] | ((uint64_t)meta[2] << 32);
                     const uint64_t sid0 = (uint64_t)meta[3] | ((uint64_t)meta[4] << 32);
                     const int it0 = (int)meta[5], n_iter = (int)meta[6];
                     const float mom = __builtin_bit_cast(float, meta[7]);
                     float* gl_out = reinterpret_cast<float*>((uint64_t)meta[8] | ((uint64_t)meta[9] << 32));
+                    // iterations [lo, hi) of the frame's chain; the last segment runs to the end and emits.  Drawing a frame's 3 x 513 initial phases
+                    // (27 Philox blocks a lane, ~12 k cycles) costs the first segment about as much as an iteration: it gets one fewer.
+                    const int span = n_iter > it0 ? n_iter - it0 : 0;
+                    const int draw = (depth > 1 && meta[0] == 0 && it0 == 0) ? 1 : 0;
+                    auto cut = [&](int k) { return k <= 0 ? 0 : k >= depth ? span : max(0, min(span, ((span + draw) * k + depth / 2) / depth - draw)); };
+                    const int lo = it0 + cut(seg), hi = it0 + cut(seg + 1);
+                    const bool last = seg == depth - 1;
+#ifdef DN_GLW_PRIO
+                    __builtin_amdgcn_s_setprio(DN_GLW_PRIO);
+#endif
                     glw_body<NFFT, STREAM>(smem, d, slot + sl.lin, init, seed, sid0, slot + sl.peak, STREAM ? nullptr : gl_out, n_iter, mom, b, lane, wv,
-                                           a.ola, a.hop_out, a.out_s16, it0, reinterpret_cast<const v2f*>(a.gl_state[s]));
-                } else if (STREAM) {
+                                           a.ola, a.hop_out, a.out_s16, lo, last ? -1 : hi, seg > 0 ? kGlwFromSeg : it0 > 0 ? kGlwFromX : kGlwFresh,
+                                           reinterpret_cast<v2f*>(a.gl_state + (size_t)s * a.state_stride));
+                    DN_WSTAMP(7);
+                }
+                if (STREAM && j == 0 && !completes) {
+                    // nothing to emit in this launch: the reference's ola[:hop] is still zero (app3.py:133,219)
                     for (int n = lane; n < kNR / 2; n += 64) {
                         if (a.out_s16) static_cast<short*>(a.hop_out)[b * (kNR / 2) + n] = 0;
                         else static_cast<float*>(a.hop_out)[b * (kNR / 2) + n] = 0.0f;
@@ -147,17 +182,17 @@ __global__ __launch_bounds__(kHopPipeThreads, (NFFT == 1536 || GLW) ? 2 : 1) voi
             // the Griffin-Lim chain is the critical path of the launch: let its waves win issue arbitration against the
             // front-half waves they share SIMDs with
             __builtin_amdgcn_s_setprio(DN_GL_PRIO);
-            const int s = (int)((frames - 1) & 1);
-            const float* slot = a.slot[s];
+            const int s = slot_behind(slot_next, 1, a.n_slots);
+            const float* slot = a.slots + (size_t)s * a.slot_stride;
             const uint32_t* meta = reinterpret_cast<const uint32_t*>(slot + sl.meta) + kSlotMeta * b;
-            const v2f* init = meta[0] ? reinterpret_cast<const v2f*>(a.slot_init[s]) : nullptr;
+            const v2f* init = meta[0] ? reinterpret_cast<const v2f*>(a.slot_init + (size_t)s * a.init_stride) : nullptr;
             const uint64_t seed = (uint64_t)meta[1] | ((uint64_t)meta[2] << 32);
             const uint64_t sid0 = (uint64_t)meta[3] | ((uint64_t)meta[4] << 32);
             const int it0 = (int)meta[5];          // iterations the frame's front workgroup already ran (head start)
             // the frame's own n_iter / momentum (those of its submit, not of this call: it0 <= n_iter by construction) and destination
             const int n_iter = (int)meta[6];
             const float mom = __builtin_bit_cast(float, meta[7]);
-            v2f* st = reinterpret_cast<v2f*>(a.gl_state[s]);
+            v2f* st = reinterpret_cast<v2f*>(a.gl_state + (size_t)s * a.state_stride);
             if (!STREAM) {
                 float* gl_out = reinterpret_cast<float*>((uint64_t)meta[8] | ((uint64_t)meta[9] << 32));
                 gl_body<NFFT, false, false>(smem, d, slot + sl.lin, nullptr, init, seed, sid0, slot + sl.peak, gl_out, n_iter, mom, b, tid,
@@ -183,8 +218,9 @@ __global__ __launch_bounds__(kHopPipeThreads, (NFFT == 1536 || GLW) ? 2 : 1) voi
             frames_in = a.ring;
         }
         if (!priming) {
-            const int s = (int)(frames & 1);
-            float* slot = a.slot[s];
+            const int s = (int)slot_next;
+            float* slot = a.slots + (size_t)s * a.slot_stride;
+            float2* slot_init = a.slot_init + (size_t)s * a.init_stride;
             stft_body<NFFT, false, true, kHopPipeThreads>(smem, d, frames_in, nullptr, slot, slot + sl.peak, DN_PEAK_NORMALIZE | DN_PRE_WINDOW, b, tid);   // P1-P6
             const int split = min(a.gl_split, a.n_iter);
             // (measured: n_fft 1536, 13 bins a lane: 106 -> 100 us per batch-256 hop; n_fft 1024, 9 bins a lane: 54.7 -> 55.2 us -- the draw's 12 KB
@@ -194,7 +230,7 @@ __global__ __launch_bounds__(kHopPipeThreads, (NFFT == 1536 || GLW) ? 2 : 1) voi
                 // The fourth wave has no column to transform and would wait here: it draws the random initial phases the head start
                 // below begins with (the same Philox blocks, so the same bits) into the slot.  One block per bin is ~10 rounds of
                 // quarter-rate integer multiplies -- 9 bins a lane cost the head start ~7 k cycles on the launch's critical path.
-                float2* dst = a.slot_init[s] + b * 3 * kBins;
+                float2* dst = slot_init + b * 3 * kBins;
                 for (int i = tid - kHopThreads; i < 3 * kBins; i += 64) {
                     const int col = i / kBins, k = i - col * kBins;
                     const v2f r = rand_angle(a.seed + frames, a.sid0 + b, col, k);
@@ -226,7 +262,7 @@ __global__ __launch_bounds__(kHopPipeThreads, (NFFT == 1536 || GLW) ? 2 : 1) voi
             }
             if (a.init_in != nullptr) {
                 const float2* src = reinterpret_cast<const float2*>(a.init_in) + b * 3 * kBins;
-                float2* dst = a.slot_init[s] + b * 3 * kBins;
+                float2* dst = slot_init + b * 3 * kBins;
                 for (int i = tid; i < 3 * kBins; i += kHopPipeThreads) dst[i] = src[i];
             }
             if (split > 0) {
@@ -235,9 +271,9 @@ __global__ __launch_bounds__(kHopPipeThreads, (NFFT == 1536 || GLW) ? 2 : 1) voi
                 if (tid >= kHopThreads) return;        // the chain is three waves wide
                 __builtin_amdgcn_s_setprio(DN_HS_PRIO); // below the pending hop's chain (3): that one ends the launch
                 gl_body<NFFT, false, false>(smem, d, slot + sl.lin, nullptr,
-                                            draw ? reinterpret_cast<const v2f*>(a.slot_init[s]) : reinterpret_cast<const v2f*>(a.init_in), a.seed + frames, a.sid0,
+                                            draw ? reinterpret_cast<const v2f*>(slot_init) : reinterpret_cast<const v2f*>(a.init_in), a.seed + frames, a.sid0,
                                             nullptr, nullptr, a.n_iter, a.mom, b, tid, nullptr, nullptr, 0, 0, split,
-                                            reinterpret_cast<v2f*>(a.gl_state[s]));
+                                            reinterpret_cast<v2f*>(a.gl_state + (size_t)s * a.state_stride));
                 __builtin_amdgcn_s_setprio(0);
                 DN_HSTAMP(4);                      // head start done
             }
@@ -249,17 +285,15 @@ __global__ __launch_bounds__(kHopPipeThreads, (NFFT == 1536 || GLW) ? 2 : 1) voi
         const unsigned int t = atomicAdd(&a.ctl->done, 1u);
         if (t == gridDim.x - 1) {
             a.ctl->done = 0;
-            if (a.front_B > 0) {
-                a.ctl->pushes = pushes + 1;
-                if (!priming) {
-                    a.ctl->frames = frames + 1;
-                    a.ctl->pending = 1;
-                } else {
-                    a.ctl->pending = 0;
-                }
-            } else {
-                a.ctl->pending = 0;      // flush
+            a.ctl->launches = launches + 1;
+            const bool fronted = a.front_B > 0 && !priming;
+            if (a.front_B > 0) a.ctl->pushes = pushes + 1;
+            if (fronted) {
+                a.ctl->front_launch[frames & 7] = launches;
+                a.ctl->frames = frames + 1;
+                a.ctl->slot_next = (int)slot_next + 1 == a.n_slots ? 0u : slot_next + 1;
             }
+            a.ctl->pending = pending - (completes ? 1u : 0u) + (fronted ? 1u : 0u);
         }
     }
 }
@@ -277,14 +311,13 @@ static void launch_hop_n(const DspDev& d, const CellDev& c, const HopArgs& a, bo
     }
 }
 
-// a.back_blocks says which Griffin-Lim schedule the caller laid the grid out for: back_B workgroups (a wavefront per column) or
-// ceil(back_B / 4) (a wavefront per stream, n_fft 1024 only)
+// a.glw: the caller laid the grid out for a wavefront per stream and chain segment (n_fft 1024 only) instead of a wavefront per column
 void launch_hop(const DspDev& d, const CellDev& c, const HopArgs& a, bool bf16, hipStream_t st) {
     const bool stream = a.ola != nullptr;
     if (d.n_fft == 1536) {
         if (stream) launch_hop_n<1536, true, false>(d, c, a, bf16, st);
         else launch_hop_n<1536, false, false>(d, c, a, bf16, st);
-    } else if (a.back_blocks != a.back_B) {
+    } else if (a.glw) {
         if (stream) launch_hop_n<1024, true, true>(d, c, a, bf16, st);
         else launch_hop_n<1024, false, true>(d, c, a, bf16, st);
     } else {
@@ -295,6 +328,8 @@ void launch_hop(const DspDev& d, const CellDev& c, const HopArgs& a, bool bf16, 
 
 __global__ void ctl_set_kernel(PipeCtl* ctl, unsigned long long pushes, unsigned long long frames, unsigned int pending) {
     ctl->pushes = pushes; ctl->frames = frames; ctl->pending = pending; ctl->done = 0;
+    ctl->launches = 0; ctl->slot_next = 0;
+    for (int i = 0; i < 8; ++i) ctl->front_launch[i] = 0;
 }
 void launch_ctl_set(PipeCtl* ctl, unsigned long long pushes, unsigned long long frames, unsigned int pending, hipStream_t st) {
     hipLaunchKernelGGL(ctl_set_kernel, dim3(1), dim3(1), 0, st, ctl, pushes, frames, pending);
@@ -354,6 +389,9 @@ void launch_frame(const DspDev& d, const CellDev& c, const FrameArgs& a, int B, 
 // diagnostic build only: the stamps of the Griffin-Lim workgroup 0 of hop_kernel / frame_kernel
 extern "C" int dn_probe_read_hop(unsigned long long* host48) {
     return (int)hipMemcpyFromSymbol(host48, HIP_SYMBOL(dn::g_gl_probe), sizeof(dn::g_gl_probe));
+}
+extern "C" int dn_probe_read_glw(unsigned long long* host32) {
+    return (int)hipMemcpyFromSymbol(host32, HIP_SYMBOL(dn::g_glw_probe), sizeof(dn::g_glw_probe));
 }
 extern "C" int dn_probe_read_hop_wg(unsigned long long* host8) {
     return (int)hipMemcpyFromSymbol(host8, HIP_SYMBOL(dn::g_hop_wg_probe), sizeof(dn::g_hop_wg_probe));

@@ -121,30 +121,40 @@ void launch_cell(const CellDev& c, const float* x, const float* hx_in, float* ou
 // be replayed indefinitely (nothing that changes from hop to hop is baked into the kernel arguments).
 struct PipeCtl {
     unsigned long long pushes;   // launches that carried a front half (streaming: the first n_fft/hop - 1 only fill the ring)
-    unsigned long long frames;   // frames whose front half (P1-P10) has run; frame f uses scratch slot f & 1
-    unsigned int pending;        // 1: the Griffin-Lim of frame frames-1 has not run yet
+    unsigned long long frames;   // frames whose front half (P1-P10) has run
+    unsigned long long launches; // launches of the pipe so far (submits, pushes and flushes)
+    unsigned int pending;        // frames whose Griffin-Lim has not finished: the most recent `pending` ones (0/1; up to the pipe's depth)
     unsigned int done;           // workgroup ticket of the launch in flight (0 between launches)
+    unsigned int slot_next;      // scratch slot the next front half writes (slots are used round robin)
+    unsigned int pad_;
+    unsigned long long front_launch[8];   // launch index in which frame f's front half ran, at [f & 7] (its chain segment s runs in launch + 1 + s)
 };
 
 // Arguments of the software-pipelined hop launch (dn_hop.hip).
 struct HopArgs {
     PipeCtl* ctl;
-    // scratch slots, each: mel [B][3][M] | residual [B][3][M] | peak [B] | meta [B][kSlotMeta] (u32, see SlotLayout) | lin [B][3][K]
-    float* slot[2];
-    float2* slot_init[2];    // [B][3][K] complex initial phases of the slot's frame (parity mode), or null
-    // front half: this hop's analysis + model + inverse mel, written to slot frames & 1
+    // scratch slots (n_slots of them, used round robin; depth + 1), each: mel [B][3][M] | residual [B][3][M] | peak [B] | meta [B][kSlotMeta] (u32, see
+    // SlotLayout) | lin [B][3][K]; per slot also the frame's initial phases [B][3][K] complex (parity mode; or null) and its parked
+    // Griffin-Lim chain (head start, chain segments; or null)
+    float* slots; size_t slot_stride;
+    float2* slot_init; size_t init_stride;
+    float2* gl_state; size_t state_stride;
+    int n_slots;
+    // front half: this hop's analysis + model + inverse mel, written to slot ctl->slot_next
     const float* frames; float* hx;
     const float* init_in;    // this hop's initial phases [B][3][K] complex (copied into the slot), or null = device RNG
     uint64_t seed, sid0;     // the frame's Griffin-Lim draws from (seed + frame index, sid0 + stream)
-    // back half: the pending hop's Griffin-Lim, read from slot (frames - 1) & 1 -- its n_iter, momentum and destination are the ones the
-    // frame's front workgroup left in the slot (these three describe THIS hop's frame)
+    // these three describe THIS hop's frame too: the back half finishes a pending hop with the n_iter, momentum and destination its own front
+    // workgroup left in the slot
     float* gl_out;
     int n_iter; float mom;
     // head start: the front workgroup, done with P1-P10 long before the launch ends, runs the first `gl_split` Griffin-Lim iterations of
-    // ITS frame and parks the chain in gl_state[slot]; the back workgroup of the next launch resumes there (0 = no head start)
-    int gl_split; float2* gl_state[2];
+    // ITS frame and parks the chain in the slot's gl_state; the back workgroup of the next launch resumes there (0 = no head start)
+    int gl_split;
     int front_B, back_B, B, C;
-    int back_blocks;         // workgroups of the back half: back_B (a wavefront per column) or ceil(back_B / 4) (a wavefront per stream, dn_glw_body.hpp)
+    // back half: back_blocks workgroups.  A wavefront per column: back_B of them, one pending hop.  A wavefront per stream (dn_glw_body.hpp): each
+    // holds spb streams x depth chain segments (spb x depth <= 4), back_blocks = ceil(back_B / spb)
+    int back_blocks, spb, depth, glw;
     // streaming mode (pipe-owned per-stream state): the front half first shifts `hop_in` into `ring` and uses the ring
     // as its frame (app3.py:178,226); the back half folds its frame into `ola` and emits `hop_out` (app3.py:219-224)
     const void* hop_in; float* ring; int in_s16; int prime;

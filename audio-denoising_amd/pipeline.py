@@ -174,6 +174,10 @@ class _Pipe:
         hs = os.environ.get("DN_GL_HEAD_START")       # experiment knob of tools/head_start_sweep.sh (the library itself reads no environment)
         if hs is not None:
             self.lib.check(self.lib.dn_pipe_set_head_start(handle, int(hs)))
+        self.depth = 1
+        dp = os.environ.get("DN_PIPE_DEPTH")           # likewise: hops of one stream in flight
+        if dp is not None:
+            self.set_depth(int(dp))
         sch = os.environ.get("DN_GL_SCHEDULE")         # likewise: 0 auto, 1 a wavefront per column, 2 a wavefront per stream
         if sch is not None:
             self.lib.check(self.lib.dn_pipe_set_gl_schedule(handle, int(sch)))
@@ -182,6 +186,14 @@ class _Pipe:
         """``_lib.DN_GL_AUTO`` / ``DN_GL_WAVE_PER_COLUMN`` / ``DN_GL_WAVE_PER_STREAM`` (dn_pipe_set_gl_schedule): how the pending hop's
         Griffin-Lim is laid out on the GPU; results are bit-identical, call between hops."""
         self.lib.check(self.lib.dn_pipe_set_gl_schedule(self.handle, int(schedule)))
+
+    def set_depth(self, depth: int) -> None:
+        """dn_pipe_set_depth: hops of ONE stream in flight (1 .. 4, n_fft 1024).  With depth D a frame's Griffin-Lim chain runs as D segments
+        in the D launches after its submit (bit-identical results): about one stream per CU then reaches the throughput of the saturated
+        regime, for D - 1 more hops of latency.  Call while nothing is in flight."""
+        with torch.cuda.device(self.dn.device):
+            self.lib.check(self.lib.dn_pipe_set_depth(self.handle, int(depth)))
+        self.depth = int(depth)
 
     def set_head_start(self, iterations: int) -> None:
         """dn_pipe_set_head_start: Griffin-Lim iterations a front workgroup runs of its own frame's chain (0 = off)."""
@@ -209,7 +221,8 @@ class HopPipeline(_Pipe):
     """Software-pipelined hops (``dn_pipe_*``): one launch per hop carries hop n's Griffin-Lim workgroups next to
     hop n+1's analysis + GRUUNet2 + inverse-mel workgroups; ``hx`` is the only dependency between hops.
     ``submit`` enqueues one hop for the whole batch on the current stream; the output of a hop is complete (in
-    stream order) after the next ``submit`` or ``flush``.  ``frames``/``out``/``hx`` must not be touched until then.
+    stream order) after the next ``submit`` (the ``depth``-th next one of a deeper pipe, ``set_depth``) or ``flush``.
+    ``frames``/``out``/``hx`` must not be touched until then.
     The Griffin-Lim of the f-th submitted hop draws from ``seed + f``.  A ``submit`` captured in a hipGraph can be
     replayed: slot parity, pending flag and frame index live on the device."""
 
@@ -293,11 +306,15 @@ class PipelinedStream(_Pipe):
             self.lib.check(self.lib.dn_pipe_reserve_parity(self.handle))
 
     def flush(self, s16: bool = False) -> torch.Tensor:
-        out = self._out(s16)
+        """Drains the pipe: the hops still in flight, ``(B, depth * hop_length)`` (zeros where nothing was pending)."""
+        outs = []
         with torch.cuda.device(self.dn.device):
             st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-            self.lib.check(self.lib.dn_pipe_stream_flush(self.handle, out.data_ptr(), int(s16), self.dn.n_iter, self.dn.momentum, st))
-        return out
+            for _ in range(self.depth):
+                out = self._out(s16)
+                self.lib.check(self.lib.dn_pipe_stream_flush(self.handle, out.data_ptr(), int(s16), self.dn.n_iter, self.dn.momentum, st))
+                outs.append(out)
+        return outs[0] if len(outs) == 1 else torch.cat(outs, dim=1)
 
     def state(self):
         """Snapshot (ring, ola, hx, frames) of the pipe-owned stream state (checkpointing live streams; call after

@@ -460,12 +460,13 @@ def test_mel_stages_at_a_filter_count_that_is_not_a_multiple_of_16(lib):
         lib.dn_dsp_destroy(h)
 
 
-def _run_pipe(lib, dsp, m, schedule, B, n_hops, g, head_start=0, stream=False, s16=False, init=None, n_iter=6):
+def _run_pipe(lib, dsp, m, schedule, B, n_hops, g, head_start=0, stream=False, s16=False, init=None, n_iter=6, depth=1, flush_after=None):
     """n_hops pipelined hops (frame mode or streaming mode) under one Griffin-Lim schedule; returns everything a hop leaves behind"""
     from audio_denoising_amd._lib import DN_GL_WAVE_PER_STREAM  # noqa: F401
     pipe = C.c_void_p()
     create = lib.dn_pipe_stream_create if stream else lib.dn_pipe_create
     lib.check(create(m, dsp, B, 0, C.byref(pipe)))
+    lib.check(lib.dn_pipe_set_depth(pipe, depth))
     lib.check(lib.dn_pipe_set_gl_schedule(pipe, schedule))
     lib.check(lib.dn_pipe_set_head_start(pipe, head_start))
     outs = []
@@ -475,6 +476,8 @@ def _run_pipe(lib, dsp, m, schedule, B, n_hops, g, head_start=0, stream=False, s
         outs = [np.zeros((B, P.n_fft), np.float32) for _ in range(n_hops)]
         for h in range(n_hops):
             lib.check(lib.dn_pipe_submit(pipe, emu.ptr(frames[h]), emu.ptr(hx), emu.ptr(outs[h]), None if init is None else emu.ptr(init[h]), 11, 3, n_iter, 0.99, None))
+            if flush_after is not None and h == flush_after:
+                lib.check(lib.dn_pipe_flush(pipe, n_iter, 0.99, None))       # a drain in the middle of the sequence
         lib.check(lib.dn_pipe_flush(pipe, n_iter, 0.99, None))
         outs.append(hx)
     else:
@@ -485,9 +488,10 @@ def _run_pipe(lib, dsp, m, schedule, B, n_hops, g, head_start=0, stream=False, s
             o = np.zeros((B, P.hop), dt)
             lib.check(lib.dn_pipe_stream_push(pipe, emu.ptr(hop_in), int(s16), emu.ptr(o), int(s16), None, 11, 3, n_iter, 0.99, None))
             outs.append(o)
-        o = np.zeros((B, P.hop), dt)
-        lib.check(lib.dn_pipe_stream_flush(pipe, emu.ptr(o), int(s16), n_iter, 0.99, None))
-        outs.append(o)
+        for _ in range(depth):
+            o = np.zeros((B, P.hop), dt)
+            lib.check(lib.dn_pipe_stream_flush(pipe, emu.ptr(o), int(s16), n_iter, 0.99, None))
+            outs.append(o)
         ring, ola, hx = np.zeros((B, P.n_fft), np.float32), np.zeros((B, P.n_fft), np.float32), np.zeros((B, 17, 5), np.float32)
         lib.check(lib.dn_pipe_stream_get_state(pipe, emu.ptr(ring), emu.ptr(ola), emu.ptr(hx), None))
         outs += [ring, ola, hx]
@@ -516,3 +520,34 @@ def test_griffinlim_one_wavefront_per_stream_is_bit_identical_to_one_per_column(
     for x, y in zip(a, b):
         assert np.array_equal(x, y)
     assert sum(int(np.abs(x.astype(np.float64)).max() > 0) for x in a) >= 3           # (the comparison is of real output)
+
+
+@pytest.mark.parametrize("depth", [2, 3, 4])
+def test_deep_pipe_runs_the_chain_in_segments_bit_identically(lib, dsp, depth):
+    """dn_pipe_set_depth: a frame's Griffin-Lim chain is cut into `depth` segments that run in the launches after its submit (one wavefront per
+    stream and segment, parked in HBM in between), `depth` hops of every stream in flight.  Frames, hx, overlap-add lines and emitted hops must
+    equal the depth-1 pipe bit for bit -- the emitted hops `depth - 1` pushes later -- also with injected phases and a drain in mid-sequence.
+    n_iter = 7 does not divide evenly (segments of 2/2/3, 1/2/2/2 ...); n_iter = 2 < depth leaves empty segments."""
+    from audio_denoising_amd._lib import DN_GL_WAVE_PER_COLUMN, DN_GL_AUTO
+    sig = load_golden("stream_S.npz")["signal"]
+    g = {"signal": sig}
+    B, n_hops = 3, depth + 2
+    m = make_model(lib, 5)
+    rg = np.random.default_rng(17)
+    init = [emu.f32(rg.random((B, 3, P.n_stft, 2))) for _ in range(n_hops)]
+    for kw in (dict(n_iter=7), dict(n_iter=7, init=init, flush_after=1), dict(n_iter=2)):
+        a = _run_pipe(lib, dsp, m, DN_GL_WAVE_PER_COLUMN, B, n_hops, g, **kw)
+        b = _run_pipe(lib, dsp, m, DN_GL_AUTO, B, n_hops, g, depth=depth, **kw)
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+        assert np.abs(a[0]).max() > 0
+    # streaming: the same samples, depth - 1 pushes later; the state after the drain is the same
+    a = _run_pipe(lib, dsp, m, DN_GL_WAVE_PER_COLUMN, B, n_hops, g, stream=True, n_iter=5)
+    b = _run_pipe(lib, dsp, m, DN_GL_AUTO, B, n_hops, g, stream=True, n_iter=5, depth=depth)
+    lib.dn_model_destroy(m)
+    ea, eb = np.concatenate(a[:-3], axis=1), np.concatenate(b[:-3], axis=1)
+    lag = (depth - 1) * P.hop
+    assert eb.shape[1] == ea.shape[1] + lag
+    assert np.array_equal(eb[:, lag:], ea) and not eb[:, :lag].any() and np.abs(ea).max() > 0
+    for x, y in zip(a[-3:], b[-3:]):
+        assert np.array_equal(x, y)

@@ -1060,3 +1060,49 @@ def test_wavefront_per_stream_schedule_matches_the_oracle_at_1024_streams(dev):
             h = ref["hx"]
             _wave_close(outs[i].cpu()[idx].numpy(), ref["out"].numpy())
     assert (hx.cpu()[idx] - h).abs().max().item() <= TOL_HX_STREAM
+
+
+@pytest.mark.parametrize("depth", [2, 3, 4])
+def test_deep_pipe_is_bit_identical_to_depth_one_at_batch_256(dev, depth):
+    """dn_pipe_set_depth (the headline's schedule): `depth` hops of every stream in flight, a frame's Griffin-Lim chain cut into `depth` segments
+    that run one wavefront per stream in consecutive launches.  Six chained hops at batch 256 with device-RNG phases, then again with injected
+    phases and a drain in mid-sequence: frames and hx equal the depth-1 pipe (wavefront per column + head start) bit for bit; streaming
+    mode emits the same int16 samples `depth - 1` pushes later and leaves the same overlap-add lines and hx."""
+    from audio_denoising_amd.pipeline import Denoiser, HopPipeline, PipelinedStream
+    p = _params("S")
+    B = 256
+    dn = Denoiser(_model(dev, 5), p.sample_rate, p.n_fft, p.hop, p.n_mels)
+    g = torch.Generator().manual_seed(600 + depth)
+    hops = [(0.1 * torch.randn(B, p.n_fft, generator=g)).to(dev) for _ in range(6)]
+    inits = [torch.rand(B, p.n_stft, 3, dtype=torch.complex64, generator=g).to(dev) for _ in range(6)]
+    for variant in ("rng", "init+drain"):
+        res = []
+        for d in (1, depth):
+            pipe = HopPipeline(dn, B)
+            pipe.set_depth(d)
+            hx = dn.init_hx(B)
+            outs = [torch.empty(B, p.n_fft, device=dev) for _ in hops]
+            for i, f in enumerate(hops):
+                pipe.submit(f, hx, outs[i], seed=77, stream_id0=5, init_angles=inits[i] if variant != "rng" else None)
+                if variant != "rng" and i == 2:
+                    pipe.flush()
+            pipe.flush()
+            torch.cuda.synchronize()
+            assert pipe.counters()[2] is False
+            res.append((hx, outs))
+        assert torch.equal(res[0][0], res[1][0])
+        for a, b in zip(res[0][1], res[1][1]):
+            assert torch.equal(a, b) and torch.isfinite(a).all()
+    sig = (0.3 * torch.randn(8, 8 * p.hop, generator=g)).clamp(-1, 1)
+    pcm = (sig * 32767.0).to(torch.int16).to(dev)
+    sres = []
+    for d in (1, depth):
+        ps = PipelinedStream(dn, 8, seed=3, stream_id0=40)
+        ps.set_depth(d)
+        o = [ps.push(pcm[:, i * p.hop:(i + 1) * p.hop].contiguous()) for i in range(8)] + [ps.flush(s16=True)]
+        ring, ola, hx, frames = ps.state()
+        torch.cuda.synchronize()
+        sres.append((torch.cat(o, 1), ola, hx))
+    lag = (depth - 1) * p.hop
+    assert torch.equal(sres[1][0][:, lag:], sres[0][0]) and not sres[1][0][:, :lag].any() and sres[0][0].abs().max().item() > 0
+    assert torch.equal(sres[0][1], sres[1][1]) and torch.equal(sres[0][2], sres[1][2])

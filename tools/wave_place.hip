@@ -73,6 +73,22 @@ static void run(const char* name, int grid, int block, int live, int rotate, int
     for (auto& kv : per_cu)
         for (int i = 0; i < 4; ++i) s[i] += kv.second[i];
     printf("   all CUs: waves per SIMD %ld %ld %ld %ld\n", s[0], s[1], s[2], s[3]);
+    // how the first half of the grid (the Griffin-Lim workgroups of a hop launch) and the second half (the front workgroups) pair up on the CUs
+    {
+        std::map<uint32_t, std::pair<int, int>> kinds;
+        for (int b = 0; b < grid; ++b) {
+            const Rec* r = nullptr;
+            for (int w = 0; w < nw; ++w) if (h[b * nw + w].hw != 0xffffffffu) { r = &h[b * nw + w]; break; }
+            if (!r) continue;
+            const uint32_t key = ((r->xcc & 15) << 16) | (((r->hw >> 13) & 7) << 8) | (((r->hw >> 12) & 1) << 4) | ((r->hw >> 8) & 15);
+            if (b < grid / 2) kinds[key].first++; else kinds[key].second++;
+        }
+        std::map<std::pair<int, int>, int> hist;
+        for (auto& kv : kinds) hist[kv.second]++;
+        printf("   CUs by (workgroups of the first half of the grid, of the second half):");
+        for (auto& kv : hist) printf("  (%d,%d) x %d", kv.first.first, kv.first.second, kv.second);
+        printf("\n");
+    }
     // the first three workgroups: which SIMDs their waves got, and on which CU
     for (int b = 0; b < 3 && b < grid; ++b) {
         printf("   block %d:", b);
@@ -93,6 +109,8 @@ int main() {
     run("3 waves (192 threads), 2 wg/CU by LDS", 2048, 192, 3, 0, 74 * 1024, spin);
     run("3 waves (192 threads), 4 wg/CU by LDS", 4096, 192, 3, 0, 36 * 1024, spin);
     run("3 waves, one wg per CU (grid 256)", 256, 192, 3, 0, 74 * 1024, spin);
-    run("4 waves, grid 512 (the batch-256 launch shape), wave 3 of the first 256 exits: see per-block", 512, 256, 4, 0, 74 * 1024, spin);
+    run("4 waves, grid 512 (the batch-256 launch shape)", 512, 256, 4, 0, 74 * 1024, spin);
+    run("4 waves, grid 512, short", 512, 256, 4, 0, 74 * 1024, 200);
+    run("4 waves, grid 2048 + 8192 shape / 4", 2560, 256, 4, 0, 74 * 1024, 2000);
     return 0;
 }
