@@ -23,7 +23,7 @@ LIB_PATH = os.environ.get("DN_LIB_PATH") or os.path.join(_HERE, "lib", "libdn_de
 SYMBOLS = (
     "dn_model_create", "dn_model_destroy", "dn_cell_forward", "dn_cell_forward_ex", "dn_cell_forward_bf16", "dn_stft_general", "dn_server_rows", "dn_istft_general", "dn_dsp_create", "dn_dsp_destroy",
     "dn_dsp_get_tables", "dn_stft", "dn_stft_mel_log1p", "dn_mel_scale", "dn_invmel", "dn_residual_invmel",
-    "dn_griffinlim", "dn_synthesis", "dn_istft", "dn_workspace_bytes", "dn_process_frame", "dn_stream_step",
+    "dn_griffinlim", "dn_griffinlim_draw_phases", "dn_synthesis", "dn_istft", "dn_workspace_bytes", "dn_process_frame", "dn_stream_step",
     "dn_pipe_create", "dn_pipe_destroy", "dn_pipe_set_model", "dn_pipe_set_head_start", "dn_pipe_set_gl_schedule", "dn_pipe_set_depth", "dn_pipe_reserve_parity", "dn_pipe_get_counters", "dn_pipe_submit", "dn_pipe_flush", "dn_pipe_stream_create", "dn_pipe_stream_push",
     "dn_pipe_stream_flush", "dn_pipe_stream_get_state", "dn_pipe_stream_set_state", "dn_momo_create", "dn_momo_destroy",
     "dn_momo_forward", "dn_last_error", "dn_abi_version",
@@ -93,6 +93,7 @@ class DnLib:
         L.dn_invmel.argtypes = [vp, p, p, i32, i32, vp]
         L.dn_residual_invmel.argtypes = [vp, p, p, p, i32, i32, vp]
         L.dn_griffinlim.argtypes = [vp, p, p, u64, u64, p, p, i32, i32, f32, vp]
+        L.dn_griffinlim_draw_phases.argtypes = [vp, u64, u64, p, i32, vp]
         L.dn_synthesis.argtypes = [vp, p, p, p, u64, u64, p, p, i32, i32, f32, vp]
         L.dn_istft.argtypes = [vp, p, p, i32, vp]
         L.dn_workspace_bytes.argtypes = [vp, i32]

@@ -681,6 +681,14 @@ int dn_griffinlim(const dn_dsp* d, const float* mag, const float* init_angles, u
     return check_launch("griffinlim_kernel");
 }
 
+int dn_griffinlim_draw_phases(const dn_dsp* d, uint64_t seed, uint64_t stream_id0, float* angles_out, int32_t B, void* stream) {
+    if (B == 0) return DN_OK;
+    if (!d || !angles_out) return fail(DN_ERR_INVALID, "dn_griffinlim_draw_phases: null argument");
+    if (B < 0) return fail(DN_ERR_INVALID, "dn_griffinlim_draw_phases: negative batch");
+    dn::launch_draw_phases(d->view, angles_out, seed, stream_id0, B, as_stream(stream));
+    return check_launch("draw_phases_kernel");
+}
+
 int dn_synthesis(const dn_dsp* d, const float* x, const float* diff, const float* init_angles, uint64_t seed, uint64_t stream_id0,
                  const float* scale, float* wave, int32_t B, int32_t n_iter, float momentum, void* stream) {
     if (B == 0) return DN_OK;      // empty batch: nothing to do (pointers of empty tensors are null)

@@ -38,6 +38,21 @@ void launch_griffinlim(const DspDev& d, const float* mag, const float* init, uin
         hipLaunchKernelGGL((griffinlim_kernel<1024, false>), dim3(B), dim3(kGlThreads), 0, st, d, mag, (const float*)nullptr, ia, seed, sid0, scale, wave, n_iter, mom);
 }
 
+// The initial phases a Griffin-Lim launch with init_angles == NULL draws for (seed, stream_id0 + stream): [B][3][K] complex, real and imaginary
+// part ~ U[0,1) independently (torchaudio's rand_init=True: torch.rand(complex64), app3.py:149-153), Philox4x32-10 keyed by
+// (seed; bin, column, stream id) -- the same rand_angle() the kernels call, so handing the result back as init_angles reproduces the launch.
+__global__ void draw_phases_kernel(float2* __restrict__ out, uint64_t seed, uint64_t sid0, int bins) {
+    const size_t b = blockIdx.x / 3;
+    const int col = blockIdx.x % 3;
+    for (int k = threadIdx.x; k < bins; k += blockDim.x) {
+        const v2f r = rand_angle(seed, sid0 + b, col, k);
+        out[(b * 3 + col) * bins + k] = make_float2(r[0], r[1]);
+    }
+}
+void launch_draw_phases(const DspDev& d, float* out, uint64_t seed, uint64_t sid0, int B, hipStream_t st) {
+    hipLaunchKernelGGL(draw_phases_kernel, dim3(3 * B), dim3(256), 0, st, reinterpret_cast<float2*>(out), seed, sid0, d.n_fft / 2 + 1);
+}
+
 // P8..P12 in one launch: residual -> mel magnitude -> inverse mel -> Griffin-Lim -> * peak.
 void launch_synthesis(const DspDev& d, const float* x, const float* diff, const float* init, uint64_t seed, uint64_t sid0,
                       const float* scale, float* wave, int B, int n_iter, float momentum, hipStream_t st) {

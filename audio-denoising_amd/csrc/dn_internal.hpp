@@ -112,6 +112,7 @@ void launch_mel(const DspDev& d, const float* mag, float* mel, int rows, hipStre
 void launch_invmel(const DspDev& d, const float* x, const float* diff, float* lin, int rows, hipStream_t st);
 void launch_griffinlim(const DspDev& d, const float* mag, const float* init, uint64_t seed, uint64_t sid0,
                        const float* scale, float* wave, int B, int n_iter, float momentum, hipStream_t st);
+void launch_draw_phases(const DspDev& d, float* out, uint64_t seed, uint64_t sid0, int B, hipStream_t st);
 void launch_synthesis(const DspDev& d, const float* x, const float* diff, const float* init, uint64_t seed, uint64_t sid0,
                       const float* scale, float* wave, int B, int n_iter, float momentum, hipStream_t st);
 void launch_cell(const CellDev& c, const float* x, const float* hx_in, float* out, float* hx_out, int B, int T,

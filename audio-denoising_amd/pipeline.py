@@ -74,6 +74,16 @@ class Denoiser:
         ia = torch.view_as_real(init_angles.to(self.device).transpose(-1, -2).contiguous())
         return ia, ia.data_ptr()
 
+    def draw_phases(self, batch: int, seed: int, stream_id0: int = 0) -> torch.Tensor:
+        """The initial Griffin-Lim phases the hop draws for (seed, stream_id0 + stream) when no ``init_angles`` are passed
+        (dn_griffinlim_draw_phases): complex64 (B, n_fft/2+1, 3), real and imaginary part ~ U[0,1) as the reference's
+        ``GriffinLim(rand_init=True)`` (app3.py:149-153).  Passing it back as ``init_angles`` reproduces the seeded call bit for bit."""
+        buf = torch.empty(batch, 3, self.n_stft, 2, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            self.lib.check(self.lib.dn_griffinlim_draw_phases(self.plan.handle, seed, stream_id0, buf.data_ptr(), batch, st))
+        return torch.view_as_complex(buf).transpose(-1, -2)
+
     # -- the hop body
     def process_frame(self, frames: torch.Tensor, hx: torch.Tensor | None = None, init_angles: torch.Tensor | None = None,
                       seed: int | None = None, stream_id0: int = 0, return_residual: bool = False):

@@ -77,37 +77,146 @@ def build_denoiser(dev, preset="S", conv="fp32"):
 
 
 def staged_kernel_times(dn, frames, hx, steps):
-    """The stages of the hop as separate launches (dn_stft_mel_log1p, dn_cell_forward[_bf16], dn_synthesis), one ABI call each with HIP
-    events in between (torch.cuda.Event on the stream the kernels are launched on).  Returns mean ms per kernel."""
+    """The stages of the hop as separate launches (dn_stft_mel_log1p, dn_cell_forward[_bf16], dn_synthesis).  Each kernel is timed by ONE
+    HIP event pair (torch.cuda.Event on the stream the kernels are launched on) around `steps` back-to-back launches of it -- an event between
+    every two launches adds several microseconds to a 6-12 us kernel.  Returns mean ms per launch."""
     import ctypes as C
     from audio_denoising_amd import _lib
     lib, plan, dev = dn.lib, dn.plan, dn.device
     B = frames.shape[0]
-    mel = torch.empty(B, 3, N_MELS, device=dev)
+    n_mels = dn.n_mels
+    mel = torch.empty(B, 3, n_mels, device=dev)
     diff = torch.empty_like(mel)
     peak = torch.empty(B, device=dev)
     out = torch.empty_like(frames)
+    hx = hx.clone()
     model_h = dn.model._native(dev)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     cell = lib.dn_cell_forward_bf16 if dn.model.conv_precision == "bf16" else lib.dn_cell_forward
-    names = ["stft_mel_log1p", "cell", "synthesis"]
-    acc = dict.fromkeys(names, 0.0)
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(steps)]
-    for s in range(steps):
-        e = ev[s]
-        e[0].record()
-        lib.check(lib.dn_stft_mel_log1p(plan.handle, frames.data_ptr(), mel.data_ptr(), peak.data_ptr(), B,
-                                        _lib.DN_PEAK_NORMALIZE | _lib.DN_PRE_WINDOW, st))
-        e[1].record()
-        lib.check(cell(model_h, mel.data_ptr(), hx.data_ptr(), diff.data_ptr(), hx.data_ptr(), B, 3, N_MELS, N_MELS // 16, st))
-        e[2].record()
-        lib.check(lib.dn_synthesis(plan.handle, mel.data_ptr(), diff.data_ptr(), None, 7 + s, 0, peak.data_ptr(), out.data_ptr(), B, GL_ITERS, 0.99, st))
-        e[3].record()
+    calls = {
+        "stft_mel_log1p": lambda s: lib.dn_stft_mel_log1p(plan.handle, frames.data_ptr(), mel.data_ptr(), peak.data_ptr(), B,
+                                                         _lib.DN_PEAK_NORMALIZE | _lib.DN_PRE_WINDOW, st),
+        "cell": lambda s: cell(model_h, mel.data_ptr(), hx.data_ptr(), diff.data_ptr(), hx.data_ptr(), B, 3, n_mels, n_mels // 16, st),
+        "synthesis": lambda s: lib.dn_synthesis(plan.handle, mel.data_ptr(), diff.data_ptr(), None, 7 + s, 0, peak.data_ptr(), out.data_ptr(), B,
+                                                dn.n_iter, 0.99, st),
+    }
+    res = {}
+    for name, call in calls.items():
+        for s_ in range(3):
+            lib.check(call(s_))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for s_ in range(steps):
+            lib.check(call(s_))
+        e1.record()
+        torch.cuda.synchronize()
+        res[name] = e0.elapsed_time(e1) / steps
+    return res
+
+
+def default_depth(batch, n_fft):
+    """Hops of one stream in flight (dn_pipe_set_depth) for throughput: enough that every CU of an MI355X (256) holds about four chains."""
+    if n_fft != 1024:
+        return 1
+    return 4 if batch <= 384 else 2 if batch < 768 else 1
+
+
+def time_pipe(dn, B, dev, steps, depth=1, seconds=None):
+    """frames/s of the software-pipelined hop at batch B and the given depth (one event pair around the run, flush included)."""
+    from audio_denoising_amd.pipeline import HopPipeline
+    g = torch.Generator().manual_seed(4321)
+    frames = (0.1 * torch.randn(B, dn.n_fft, generator=g)).to(dev)
+    hx = dn.init_hx(B)
+    out = torch.empty_like(frames)
+    pipe = HopPipeline(dn, B)
+    pipe.set_depth(depth)
+    for _ in range(30):
+        pipe.submit(frames, hx, out, seed=1, check_weights=False)
+    pipe.flush()
     torch.cuda.synchronize()
-    for s in range(steps):
-        for i, n in enumerate(names):
-            acc[n] += ev[s][i].elapsed_time(ev[s][i + 1])
-    return {n: acc[n] / steps for n in names}
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pipe.submit(frames, hx, out, seed=1, check_weights=False)
+    pipe.flush()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    return B * steps / el, 1e3 * el / steps
+
+
+def extra_measurements(args, dev, budget_steps=1500):
+    """Bounded side numbers carried in the same JSON line (about a second each): BASELINE config 3 (bf16 MFMA conv tiles), config 5's per-GPU
+    share (1,024 streams, ONE hipGraph-captured push replayed per hop), the reference app's own parameters (n_fft 1536), the saturated regime,
+    and the latency of ONE stream (batch 1: how the reference app runs, app3.py:178) through the unpipelined and the pipelined streaming step."""
+    from audio_denoising_amd.pipeline import DenoiserStream, PipelinedStream
+    res = {}
+    # config 3
+    dnb = build_denoiser(dev, "S", "bf16")
+    v, ms = time_pipe(dnb, BATCH, dev, 1000, default_depth(BATCH, N_FFT))
+    g = torch.Generator().manual_seed(1)
+    fr = (0.1 * torch.randn(BATCH, N_FFT, generator=g)).to(dev)
+    kt = staged_kernel_times(dnb, fr, dnb.init_hx(BATCH), 200)
+    conv = CONV_FLOP_PER_FRAME * BATCH / (kt["cell"] * 1e-3) / 1e12
+    res["config3_bf16"] = {"value": round(v, 1), "unit": "frames/s", "ms_per_step": round(ms, 4), "streams": BATCH,
+                           "pipeline_depth": default_depth(BATCH, N_FFT), "cell_ms": round(kt["cell"], 4),
+                           "conv_mfma": {"achieved": round(conv, 3), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(conv / PEAK_BF16_TFLOPS, 5)}}
+    # config 5, one GPU's share: 1,024 streams, streaming state on the device, one captured push per hop
+    dn = build_denoiser(dev, "S", "fp32")
+    B5 = 1024
+    ps = PipelinedStream(dn, B5)
+    hop = (0.1 * torch.randn(B5, dn.hop, generator=g)).to(dev)
+    hop_out = torch.empty_like(hop)
+    graph = ps.graph_step(hop, hop_out)
+    for _ in range(20):
+        graph.replay()
+    torch.cuda.synchronize()
+    n5 = 400
+    t0 = time.perf_counter()
+    for _ in range(n5):
+        graph.replay()
+    ps.flush()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    res["config5_stream_graph_1024"] = {"value": round(B5 * n5 / el, 1), "unit": "frames/s", "ms_per_step": round(1e3 * el / n5, 4), "streams": B5,
+                                        "mode": "dn_pipe_stream_push captured once in a hipGraph, replayed per hop; ring/overlap-add/hx resident"}
+    # saturated regime (wavefront-per-stream Griffin-Lim)
+    for b, n in ((1024, 300), (8192, 40)):
+        v, ms = time_pipe(dn, b, dev, n, 1)
+        res[f"batch_{b}"] = {"value": round(v, 1), "unit": "frames/s", "ms_per_step": round(ms, 4),
+                             "fp32_frac": round(TOTAL_FLOP_PER_FRAME * v / 1e12 / PEAK_FP32_TFLOPS, 4)}
+    # the reference app's own STFT parameters (app3.py:29-33): 48 kHz, n_fft 1536, 64 mels
+    dnr = build_denoiser(dev, "R1", "fp32")
+    v, ms = time_pipe(dnr, BATCH, dev, 600, 1)
+    res["r1_app_params"] = {"value": round(v, 1), "unit": "frames/s", "ms_per_step": round(ms, 4), "streams": BATCH, "n_fft": 1536, "n_mels": 64,
+                            "sample_rate": 48000, "fp32_frac": round(9.39e6 * v / 1e12 / PEAK_FP32_TFLOPS, 4)}
+    # one stream: latency of a hop (synchronised after every hop), beside cpu_baseline.batch1_value
+    lat = {}
+    ds = DenoiserStream(dn, 1)
+    chunk = (0.1 * torch.randn(1, dn.hop, generator=g)).to(dev)
+    ds.push(torch.cat([chunk, chunk], 1))
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(200):
+        t0 = time.perf_counter()
+        ds.push(chunk)
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    lat["dn_stream_step"] = round(1e6 * float(np.median(ts)), 1)
+    p1 = PipelinedStream(dn, 1)
+    o1 = torch.empty(1, dn.hop, device=dev)
+    for _ in range(5):
+        p1.push_(chunk, o1, check_weights=False)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(200):
+        t0 = time.perf_counter()
+        p1.push_(chunk, o1, check_weights=False)
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    lat["dn_pipe_stream_push"] = round(1e6 * float(np.median(ts)), 1)
+    lat["note"] = ("median wall time of one hop of ONE stream, host call to synchronised result (the pipelined push returns the previous hop's "
+                   "samples); a 16 kHz / hop 512 stream delivers a hop every 32,000 us")
+    res["latency_us_b1"] = lat
+    return res
 
 
 def usable_cores():
@@ -177,6 +286,8 @@ def side_measurement(args, dn, B, dev):
     mode = "frames"
     if args.stream:
         ps = PipelinedStream(dn, B)
+        if args.depth > 0:
+            ps.set_depth(args.depth)
         hop = (0.1 * torch.randn(B, dn.hop, generator=g)).to(dev)
         hop_out = torch.empty_like(hop)
         mode = "stream"
@@ -210,6 +321,8 @@ def side_measurement(args, dn, B, dev):
     else:
         frames = (0.1 * torch.randn(B, dn.n_fft, generator=g)).to(dev)
         pipe = HopPipeline(dn, B)
+        pipe.set_depth(args.depth if args.depth > 0 else default_depth(B, dn.n_fft))
+        mode = f"frames, depth {pipe.depth}"
 
         def step(i):
             pipe.submit(frames, hx, out, seed=1000, check_weights=False)
@@ -360,6 +473,9 @@ def main():
     ap.add_argument("--pcie", action="store_true", help="side measurement: frames arrive in pinned host memory and results return to it every hop")
     ap.add_argument("--stream", action="store_true", help="streaming mode (BASELINE config 5): pipe-owned ring/overlap-add/hx state, one hop of new samples per step")
     ap.add_argument("--graph", action="store_true", help="with --stream: replay ONE hipGraph-captured push per step")
+    ap.add_argument("--depth", type=int, default=0, help="hops of one stream in flight (dn_pipe_set_depth, 1..4); 0 = the throughput default for the batch "
+                                                            "(4 up to 384 streams, 2 below 768, else 1); 1 = output after the next hop")
+    ap.add_argument("--no-extras", action="store_true", help="skip the bounded side measurements carried in the line (config 3, config 5, R1, batch-1 latency)")
     args = ap.parse_args()
 
     rehearsal = os.environ.get("DN_BENCH_REHEARSAL") == "1"
@@ -398,7 +514,7 @@ def main():
     from audio_denoising_amd.shard import shard_range
     B = args.batch
     dn = Rehearsal() if rehearsal else build_denoiser(dev, args.preset, args.conv)
-    if on_gpu and (args.preset != "S" or args.stream or args.pcie):
+    if on_gpu and (args.preset != "S" or args.stream or args.pcie or (B != BATCH and world == 1)):
         return side_measurement(args, dn, B, dev)
     lo, hi = shard_range(B * world, world, rank)          # this rank's global stream ids
     g = torch.Generator().manual_seed(1234 + rank)
@@ -408,11 +524,15 @@ def main():
 
     # Product configuration for throughput: software-pipelined hops (dn_pipe_*): ONE launch per hop whose workgroups are
     # hop n's Griffin-Lim next to hop n+1's analysis + model + inverse mel; hx is the only inter-hop dependency.
+    depth = 1
     if rehearsal:
         pipe = dn.pipe(B)
     else:
         from audio_denoising_amd.pipeline import HopPipeline
         pipe = None if args.serial else HopPipeline(dn, B)
+        if pipe is not None:
+            depth = args.depth if args.depth > 0 else default_depth(B, N_FFT)
+            pipe.set_depth(depth)
 
     def step(i):
         if pipe is None:
@@ -459,7 +579,13 @@ def main():
     if world > 1 and pipe is not None:
         # a side measurement must never cost the headline line: any failure in it (on every rank alike: the loop is collective) is reported, not raised
         try:
-            ingress = ingress_variant(dn, pipe, B, world, rank, dev, lo, args.steps, args.warmup, dist, backend, fence, on_gpu)
+            # (its double buffering is written for the one-hop pipe: hop i-1 completes during launch i)
+            ipipe = dn.pipe(B) if rehearsal else HopPipeline(dn, B)
+
+            def ifence():
+                ipipe.flush()
+                fence()
+            ingress = ingress_variant(dn, ipipe, B, world, rank, dev, lo, args.steps, args.warmup, dist, backend, ifence, on_gpu)
         except Exception as e:          # noqa: BLE001
             ingress = {"ingress": "scatter_gather", "error": f"{type(e).__name__}: {e}"[:300]}
 
@@ -482,6 +608,9 @@ def main():
         }
         if ingress is not None:
             line["ingress_variant"] = ingress
+            line["ingress_ok"] = "error" not in ingress and bool(ingress.get("root_output_finite", False))
+        line["ranks"] = {"seen": ranks_seen, "backend": backend if world > 1 else None,
+                         "rank0_device": (torch.cuda.get_device_name(dev) if on_gpu else "cpu"), "local_rank": local}
     if rank == 0 and on_gpu:
         # the same K steps strictly one after another, nothing overlapped (dn_process_frame: one launch, no added hop of latency)
         torch.cuda.synchronize()
@@ -490,7 +619,9 @@ def main():
             dn.process_frame_(frames, hx, out, seed=5000 + i, stream_id0=lo)
         torch.cuda.synchronize()
         serial_ms = 1e3 * (time.perf_counter() - ts) / args.steps
-        kt = staged_kernel_times(dn, frames, hx, min(args.steps, 100))
+        kt = staged_kernel_times(dn, frames, hx, 200)
+        # the same workload through the one-hop pipe (output after the next submit): wavefront per column + head start
+        depth1_ms = time_pipe(dn, B, dev, max(args.steps, 200), 1)[1] if (depth != 1 or pipe is None) else ms
         # dominant kernel of the timed region: hop_kernel.  Mean launch duration from HIP events recorded on the launch
         # stream around a run of back-to-back launches (each launch = one whole hop of work for the batch).
         if pipe is not None:
@@ -505,7 +636,8 @@ def main():
             pipe.flush()
             torch.cuda.synchronize()
             dom_ms = e0.elapsed_time(e1) / n_ev
-            dom_name, dom_flop = "hop_kernel (hop n Griffin-Lim blocks + hop n+1 analysis/model/inverse-mel blocks)", TOTAL_FLOP_PER_FRAME
+            dom_name, dom_flop = ("hop_kernel (Griffin-Lim blocks of the hops in flight + this hop's analysis/model/inverse-mel blocks: "
+                                  "one launch = one hop of work for every stream)"), TOTAL_FLOP_PER_FRAME
             dom_note = ("fp32-VALU bound (78 % of the flops are FFT butterflies on the fp32 vector ALU, the convs run on fp32 MFMA; vector and matrix "
                         "fp32 peaks are both 157.3 TF, so one roof serves both); "
                         "algorithmic = 6.50 MFLOP per frame (198 rFFT-1024 x 25,600 + mel + convs + inverse mel) x 256 frames per launch")
@@ -541,12 +673,21 @@ def main():
                           "achieved": round(conv_ach, 3), "peak": conv_peak, "unit": "TFLOP/s", "frac": round(conv_ach / conv_peak, 5),
                           "note": "0.24 GFLOP per batch-256 launch is 1.5 us at the fp32 peak: structurally latency-bound (SURVEY section 7)"},
             "schedule": "unpipelined, 1 launch per hop (dn_process_frame), no added latency" if pipe is None
-                        else "software-pipelined, 1 launch per hop (dn_pipe_submit): output delayed by one hop",
+                        else f"software-pipelined, 1 launch per hop (dn_pipe_submit), depth {depth}: {depth} hops of every stream in flight, "
+                             f"output complete {depth} launch(es) after its submit" + ("" if depth == 1 else
+                             "; the Griffin-Lim chain of a frame runs as one segment per launch, one wavefront per stream and segment (bit-identical to depth 1)"),
+            "pipeline_depth": depth if pipe is not None else 0,
+            "depth1_ms_per_step": round(depth1_ms, 4),
             "serial_ms_per_step": round(serial_ms, 4),
             "whole_path": {"tflops": round(TOTAL_FLOP_PER_FRAME * value / 1e12, 3),
                            "fp32_frac": round(TOTAL_FLOP_PER_FRAME * value / 1e12 / (PEAK_FP32_TFLOPS * world), 4),
                            "hbm_frac": round(HBM_BYTES_PER_FRAME * value / 1e9 / (PEAK_HBM_GBS * world), 6)},
         })
+        if world == 1 and not args.no_extras:
+            try:
+                line.update(extra_measurements(args, dev))
+            except Exception as e:          # noqa: BLE001  (a side measurement must never cost the headline line)
+                line["extras_error"] = f"{type(e).__name__}: {e}"[:300]
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
     if dist is not None:

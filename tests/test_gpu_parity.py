@@ -25,6 +25,19 @@ TOL_WAVE_MAX = 2e-2
 # hx after a chain of hops fed by the fp32 DSP front end (the model input itself differs from the oracle's by ~2e-5, P5): measured
 # <= 6e-5 after 30 chained steps (stream_S), bound 2e-4.  (The model stage alone holds 1e-4: test_gruunet2_chain_of_20_hops.)
 TOL_HX_STREAM = 2e-4
+# Guard bands next to the north_star bars: 10x what is measured on the MI355X (tools/parity_margins.py, profiles/r03_parity_margins.txt), so that a
+# regression two orders below the bars still fails.  On the committed goldens (S / R2 / R1, 8 frames each, shared Griffin-Lim phases) the hop
+# measures: residual <= 2.9e-6, hx <= 4.2e-7, waveform max-abs <= 2.0e-6, RMS <= 3.7e-7.
+GUARD_RESIDUAL = 5e-5
+GUARD_HX = 1e-5
+GUARD_WAVE_MAX = 5e-5
+GUARD_WAVE_RMS = 1e-5
+# All 256 random frames of the metric's batch: residual 5.8e-6, hx 6.1e-7; the waveform error is NOT uniform over streams -- 32 Griffin-Lim iterations
+# amplify rounding differences by a factor that depends on the frame (~100x typical), a few streams in 256 end two orders above
+# the median -- measured over the batch RMS 5.2e-5 and max-abs 1.4e-3 (signal RMS 8.9e-3), median per-stream RMS ~1e-6.
+GUARD_B256_WAVE_RMS = 5e-4
+GUARD_B256_WAVE_MAX = 1e-2
+GUARD_B256_STREAM_MEDIAN_RMS = 2e-5
 
 
 def _wave_close(got, ref, scale=1.0):
@@ -238,9 +251,10 @@ def test_process_frame_matches_oracle_golden(dev, tag):
     dn = Denoiser(_model(dev, p.num_compressed_bins), p.sample_rate, p.n_fft, p.hop, p.n_mels)
     frames = torch.from_numpy(g["frames"]).to(dev)
     out, hx, resid = dn.process_frame(frames, None, init_angles=torch.from_numpy(g["init_angles"]).to(dev), return_residual=True)
-    assert np.abs(resid.cpu().numpy() - g["predicted_diff"]).max() <= TOL_RESIDUAL
-    assert np.abs(hx.cpu().numpy() - g["hx"]).max() <= TOL_RESIDUAL
-    _wave_close(out.cpu().numpy(), g["out"])
+    assert np.abs(resid.cpu().numpy() - g["predicted_diff"]).max() <= GUARD_RESIDUAL <= TOL_RESIDUAL
+    assert np.abs(hx.cpu().numpy() - g["hx"]).max() <= GUARD_HX
+    rms, mx = _wave_close(out.cpu().numpy(), g["out"])
+    assert rms <= GUARD_WAVE_RMS and mx <= GUARD_WAVE_MAX, (rms, mx)
     # silent / sub-threshold streams (peak <= 1e-6 -> no normalisation, app3.py:182-186) stay finite and match the oracle
     assert torch.isfinite(out).all()
     assert np.abs(out.cpu().numpy()[4:6] - g["out"][4:6]).max() <= 1e-3
@@ -283,8 +297,8 @@ def test_process_frame_at_other_filter_counts_matches_the_oracle(dev, n_mels):
 
 
 def test_process_frame_full_batch_vs_oracle_sample_and_shard_invariance(dev):
-    """BASELINE config 2: batch 256, S params.  A bounded sample of streams is checked against the oracle;
-    the whole batch is checked by the shard property (two half-batches with global stream ids == one batch)."""
+    """BASELINE config 2: batch 256, S params.  EVERY stream is checked against the oracle (guard bands beside the north_star bars);
+    the device-RNG path by the shard property (two half-batches with global stream ids == one batch)."""
     from audio_denoising_amd.pipeline import Denoiser
     from oracle import dsp_ref, pipeline_ref
     p = pipeline_ref.PARAMS_S
@@ -293,12 +307,16 @@ def test_process_frame_full_batch_vs_oracle_sample_and_shard_invariance(dev):
     frames = 0.1 * torch.randn(256, p.n_fft, generator=g)
     init = torch.rand(256, p.n_stft, 3, dtype=torch.complex64, generator=torch.Generator().manual_seed(4321))
     out, hx, resid = dn.process_frame(frames.to(dev), None, init_angles=init.to(dev), return_residual=True)
-    idx = torch.arange(0, 256, 32)
     fb = dsp_ref.melscale_fbanks(p.n_stft, p.n_mels, p.sample_rate)
-    with torch.no_grad():
-        ref = pipeline_ref.process_frame(_state_dict("dari_tult"), frames[idx], torch.zeros(len(idx), 17, 5), p, fb, init_angles=init[idx])
-    assert (resid.cpu()[idx] - ref["predicted_diff"]).abs().max().item() <= TOL_RESIDUAL
-    _wave_close(out.cpu()[idx].numpy(), ref["out"].numpy())
+    with torch.no_grad():       # ALL 256 streams (the CPU oracle takes ~0.3 s for them)
+        ref = pipeline_ref.process_frame(_state_dict("dari_tult"), frames, torch.zeros(256, 17, 5), p, fb, init_angles=init)
+    assert (resid.cpu() - ref["predicted_diff"]).abs().max().item() <= GUARD_RESIDUAL
+    assert (hx.cpu() - ref["hx"]).abs().max().item() <= GUARD_HX
+    rms, mx = _wave_close(out.cpu().numpy(), ref["out"].numpy())
+    per_stream = (out.cpu() - ref["out"]).pow(2).mean(dim=1).sqrt().numpy()
+    print(f"batch 256, all streams: waveform RMS {rms:.2e} max-abs {mx:.2e}; per-stream RMS median {np.median(per_stream):.2e} "
+          f"p90 {np.quantile(per_stream, 0.9):.2e} max {per_stream.max():.2e}")
+    assert rms <= GUARD_B256_WAVE_RMS and mx <= GUARD_B256_WAVE_MAX and np.median(per_stream) <= GUARD_B256_STREAM_MEDIAN_RMS
     # device-RNG path: sharding must not change a single bit
     fd = frames.to(dev)
     whole, hw = dn.process_frame(fd, None, seed=99, stream_id0=0)
@@ -861,7 +879,7 @@ def test_config3_bf16_conv_tiles_inside_the_whole_hop_batch256(dev):
     frames = 0.1 * torch.randn(256, p.n_fft, generator=g)
     init = torch.rand(256, p.n_stft, 3, dtype=torch.complex64, generator=torch.Generator().manual_seed(4321))
     out, hx, resid = dn.process_frame(frames.to(dev), None, init_angles=init.to(dev), return_residual=True)
-    idx = torch.arange(0, 256, 16)
+    idx = torch.arange(0, 256)           # every stream
     fb = dsp_ref.melscale_fbanks(p.n_stft, p.n_mels, p.sample_rate)
     with torch.no_grad():
         ref = pipeline_ref.process_frame(_state_dict("dari_tult"), frames[idx], torch.zeros(len(idx), 17, 5), p, fb, init_angles=init[idx])
@@ -1106,3 +1124,112 @@ def test_deep_pipe_is_bit_identical_to_depth_one_at_batch_256(dev, depth):
     lag = (depth - 1) * p.hop
     assert torch.equal(sres[1][0][:, lag:], sres[0][0]) and not sres[1][0][:, :lag].any() and sres[0][0].abs().max().item() > 0
     assert torch.equal(sres[0][1], sres[1][1]) and torch.equal(sres[0][2], sres[1][2])
+
+
+@pytest.mark.parametrize("depth", [1, 4])
+def test_pipelined_hop_at_batch_256_directly_against_the_oracle(dev, depth):
+    """The configuration the bench times, compared with the oracle DIRECTLY (not through pipelined == serial): HopPipeline at batch 256 with
+    its defaults (depth 1: a wavefront per column and the head start; depth 4: the bench's default -- chain segments, a wavefront per stream),
+    three chained hops with injected Griffin-Lim phases (dn_pipe_reserve_parity), every stream: waveform and carried hx."""
+    from audio_denoising_amd.pipeline import Denoiser, HopPipeline
+    from oracle import dsp_ref, pipeline_ref
+    p = pipeline_ref.PARAMS_S
+    dn = Denoiser(_model(dev, 5), p.sample_rate, p.n_fft, p.hop, p.n_mels)
+    g = torch.Generator().manual_seed(2024)
+    hops = [0.1 * torch.randn(256, p.n_fft, generator=g) for _ in range(3)]
+    inits = [torch.rand(256, p.n_stft, 3, dtype=torch.complex64, generator=g) for _ in range(3)]
+    pipe = HopPipeline(dn, 256)
+    pipe.set_depth(depth)
+    hx = dn.init_hx(256)
+    outs = [torch.empty(256, p.n_fft, device=dev) for _ in hops]
+    for i in range(3):
+        pipe.submit(hops[i].to(dev), hx, outs[i], seed=0, init_angles=inits[i].to(dev))
+    pipe.flush()
+    torch.cuda.synchronize()
+    fb = dsp_ref.melscale_fbanks(p.n_stft, p.n_mels, p.sample_rate)
+    sd = _state_dict("dari_tult")
+    h = torch.zeros(256, 17, 5)
+    with torch.no_grad():
+        for i in range(3):
+            ref = pipeline_ref.process_frame(sd, hops[i], h, p, fb, init_angles=inits[i])
+            h = ref["hx"]
+            rms, mx = _wave_close(outs[i].cpu().numpy(), ref["out"].numpy())
+            per_stream = (outs[i].cpu() - ref["out"]).pow(2).mean(dim=1).sqrt().numpy()
+            assert rms <= GUARD_B256_WAVE_RMS and mx <= GUARD_B256_WAVE_MAX and np.median(per_stream) <= GUARD_B256_STREAM_MEDIAN_RMS, (i, rms, mx)
+    assert (hx.cpu() - h).abs().max().item() <= GUARD_HX
+
+
+@pytest.mark.parametrize("short,F", [("dari_tult", 64), ("dari_tult", 80), ("dari_tult2", 64)])
+def test_checkpoint_in_the_reference_format_loads_and_runs_on_the_gpu(dev, tmp_path, short, F):
+    """SURVEY 8(f)-3 on the GPU tier: a `.pth` written with torch.save in the reference's own layout (app.py:75-91: config,
+    model_state_dict, optimizer_state_dict, loss_record ...) from the committed weight blob -> checkpoint.load_model(path, device) as the
+    app's loader does it (app3.py:59-116) -> HIP forward, against the golden produced by the reference's own GRUUNet2.  F = 80 goes through
+    `num_compressed_bins=5` on a checkpoint that stores 4; the other spelling the loader accepts (hparams /
+    state_dict) gives the same native weights."""
+    from audio_denoising_amd import checkpoint as ck
+    stored = dict(CFG, num_compressed_bins=4)
+    path = str(tmp_path / "checkpoint.pth")
+    torch.save({"config": stored, "model_state_dict": _state_dict(short), "optimizer_state_dict": {}, "last_epoch": 7,
+                "loss_record": {"train": [7.43], "test": []}, "total_training_iters": 92637}, path)
+    m = ck.load_model(path, device=dev, num_compressed_bins=None if F == 64 else 5)
+    assert not m.training and next(m.parameters()).is_cuda and m.num_compressed_bins == F // 16
+    g = load_golden(f"cell_{short}_B4_T3_F{F}.npz")
+    x, hx0 = torch.from_numpy(g["x"]).to(dev), torch.from_numpy(g["hx0"]).to(dev)
+    with torch.no_grad():
+        out, hx1 = m(x, hx0)
+    assert (out.cpu() - torch.from_numpy(g["out"])).abs().max().item() <= GUARD_RESIDUAL
+    assert (hx1.cpu() - torch.from_numpy(g["hx1"])).abs().max().item() <= GUARD_HX * 10
+    path2 = str(tmp_path / "other_spelling.pth")
+    torch.save({"hparams": stored, "state_dict": _state_dict(short)}, path2)
+    m2 = ck.load_model(path2, device=dev, num_compressed_bins=F // 16)
+    with torch.no_grad():
+        out2, _ = m2(x, hx0)
+    assert torch.equal(out, out2)
+    # the flat export is what the C ABI takes: byte-equal to the committed blob
+    b, _ = ck.export_flat(path, str(tmp_path / "flat"))
+    assert np.array_equal(np.fromfile(b, dtype=np.float32), np.fromfile(os.path.join(GOLDEN, f"weights_{short}.bin"), dtype=np.float32))
+
+
+def test_device_rng_known_answers_and_statistics(dev):
+    """rand_init=True (app3.py:149-153 -> torch.rand(complex64)) is replaced by an on-device Philox4x32-10.  (1) Bit-exact: 700 streams x 3 x 513
+    complex draws against the independent numpy restatement (oracle/philox_ref.py, pinned by Random123's published known-answer vectors; the
+    first vector is bin 0 of stream 0 at seed 0), with a seed and stream ids that use the high words.  (2) Statistics over 1.08 M complex
+    draws: mean, variance and a Kolmogorov-Smirnov test of real and imaginary parts against U[0,1), and no correlation between real and
+    imaginary part, neighbouring bins, columns, neighbouring streams and consecutive frames (seed + 1).  (3) A seeded hop == the same hop fed
+    these phases."""
+    from scipy import stats
+    from audio_denoising_amd.pipeline import Denoiser
+    from oracle import philox_ref
+    p = _params("S")
+    dn = Denoiser(_model(dev, 5), p.sample_rate, p.n_fft, p.hop, p.n_mels)
+    for ctr, key, out in philox_ref.KAT:
+        assert tuple(int(x) for x in philox_ref.philox4x32_10(*ctr, *key)) == out
+    z0 = dn.draw_phases(1, 0, 0).cpu().numpy()
+    assert z0[0, 0, 0].real == np.float32((0x6627e8d5 >> 8) / 16777216.0) and z0[0, 0, 0].imag == np.float32((0xe169c58d >> 8) / 16777216.0)
+    B, seed, sid0 = 700, 0xC0FFEE1234567, (1 << 33) + 5
+    z = dn.draw_phases(B, seed, sid0).cpu().numpy()
+    assert np.array_equal(z[:24], philox_ref.draw_phases(seed, sid0, 24, p.n_stft))
+    assert np.array_equal(z[-3:], philox_ref.draw_phases(seed, sid0 + B - 3, 3, p.n_stft))
+    z1 = dn.draw_phases(B, seed + 1, sid0).cpu().numpy()              # the next frame of the same streams
+    re, im = z.real.astype(np.float64), z.imag.astype(np.float64)
+    n = re.size
+    assert n >= 1_000_000 and re.min() >= 0.0 and re.max() < 1.0 and im.min() >= 0.0 and im.max() < 1.0
+    for x in (re, im):
+        assert abs(x.mean() - 0.5) <= 5 * np.sqrt(1 / 12 / n)                     # 5 sigma of the sample mean
+        assert abs(x.var() - 1 / 12) <= 5 * np.sqrt(1 / 180 / n)                  # var of the sample variance of U[0,1) ~ 1/(180 n)
+        assert stats.kstest(x.ravel(), "uniform").pvalue > 1e-4
+    def corr(a, b):
+        return float(np.corrcoef(a.ravel(), b.ravel())[0, 1])
+    bound = 5 / np.sqrt(n / 2)
+    assert abs(corr(re, im)) <= bound
+    assert abs(corr(re[:, :-1, :], re[:, 1:, :])) <= bound                        # neighbouring bins
+    assert abs(corr(re[:, :, 0], re[:, :, 1])) <= 5 / np.sqrt(n / 3) and abs(corr(im[:, :, 1], im[:, :, 2])) <= 5 / np.sqrt(n / 3)   # columns
+    assert abs(corr(re[:-1], re[1:])) <= bound                                    # neighbouring streams
+    assert abs(corr(re, z1.real.astype(np.float64))) <= bound and abs(corr(im, z1.imag.astype(np.float64))) <= bound                 # consecutive frames
+    assert len(np.unique(z.view(np.uint64))) > 0.999 * n                          # (24-bit mantissas: a handful of repeated pairs at most)
+    # a seeded hop is the hop fed exactly these phases
+    g = torch.Generator().manual_seed(8)
+    frames = (0.1 * torch.randn(16, p.n_fft, generator=g)).to(dev)
+    a, ha = dn.process_frame(frames, None, seed=seed, stream_id0=sid0)
+    b, hb = dn.process_frame(frames, None, init_angles=dn.draw_phases(16, seed, sid0))
+    assert torch.equal(a, b) and torch.equal(ha, hb)
