@@ -91,6 +91,7 @@ struct SlotLayout {
 #ifdef DN_PROBE
 // diagnostic build only: when the two kinds of workgroups of one launch start and finish (workgroups 0 and back_B of the last launch)
 static __device__ unsigned long long g_hop_wg_probe[8];
+static __device__ unsigned int g_hop_blk_hw[2048];          // where every workgroup of the last launch ran: HW_ID | XCC_ID << 28 (tools/glw_probe.py census)
 #define DN_HSTAMP(id) do { if (tid == 0 && (blockIdx.x == 0 || (int)blockIdx.x == a.back_blocks)) { unsigned long long t_; \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); g_hop_wg_probe[id] = t_; } } while (0)
 #else
@@ -123,6 +124,14 @@ __global__ __launch_bounds__(kHopPipeThreads, (NFFT == 1536 || GLW) ? 2 : 1) voi
     const unsigned int pending = a.ctl->pending, slot_next = a.ctl->slot_next;
     const SlotLayout sl(a.B, d.n_mels, kBins);
     const bool priming = STREAM && pushes < (unsigned long long)a.prime;
+#ifdef DN_PROBE
+    if (tid == 0 && blockIdx.x < 2048) {
+        unsigned int hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_hop_blk_hw[blockIdx.x] = (hw & 0x0fffffffu) | (xcc << 28);
+    }
+#endif
     // the oldest frame in flight completes in this launch when this is its last segment (wavefront per column: depth 1, always)
     const int depth = GLW ? a.depth : 1;
     const bool completes = pending > 0 && launches - a.ctl->front_launch[(frames - pending) & 7] == (unsigned long long)depth;
@@ -389,6 +398,9 @@ void launch_frame(const DspDev& d, const CellDev& c, const FrameArgs& a, int B, 
 // diagnostic build only: the stamps of the Griffin-Lim workgroup 0 of hop_kernel / frame_kernel
 extern "C" int dn_probe_read_hop(unsigned long long* host48) {
     return (int)hipMemcpyFromSymbol(host48, HIP_SYMBOL(dn::g_gl_probe), sizeof(dn::g_gl_probe));
+}
+extern "C" int dn_probe_read_blk_hw(unsigned int* host2048) {
+    return (int)hipMemcpyFromSymbol(host2048, HIP_SYMBOL(dn::g_hop_blk_hw), sizeof(dn::g_hop_blk_hw));
 }
 extern "C" int dn_probe_read_glw(unsigned long long* host32) {
     return (int)hipMemcpyFromSymbol(host32, HIP_SYMBOL(dn::g_glw_probe), sizeof(dn::g_glw_probe));

@@ -102,7 +102,7 @@ def staged_kernel_times(dn, frames, hx, steps):
     }
     res = {}
     for name, call in calls.items():
-        for s_ in range(3):
+        for s_ in range(max(3, steps // 2)):            # (warm: also keeps the clocks up between the measurements)
             lib.check(call(s_))
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -121,6 +121,15 @@ def default_depth(batch, n_fft):
     return 4 if batch <= 384 else 2 if batch < 768 else 1
 
 
+def prewarm(step, seconds=0.3):
+    """Untimed: bring the GPU out of its idle power state (a cold GPU runs the first hundreds of hops at roughly half clock)."""
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < seconds:
+        for _ in range(50):
+            step()
+        torch.cuda.synchronize()
+
+
 def time_pipe(dn, B, dev, steps, depth=1, seconds=None):
     """frames/s of the software-pipelined hop at batch B and the given depth (one event pair around the run, flush included)."""
     from audio_denoising_amd.pipeline import HopPipeline
@@ -130,8 +139,7 @@ def time_pipe(dn, B, dev, steps, depth=1, seconds=None):
     out = torch.empty_like(frames)
     pipe = HopPipeline(dn, B)
     pipe.set_depth(depth)
-    for _ in range(30):
-        pipe.submit(frames, hx, out, seed=1, check_weights=False)
+    prewarm(lambda: pipe.submit(frames, hx, out, seed=1, check_weights=False), 0.3 if B <= 1024 else 0.1)
     pipe.flush()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -154,7 +162,7 @@ def extra_measurements(args, dev, budget_steps=1500):
     v, ms = time_pipe(dnb, BATCH, dev, 1000, default_depth(BATCH, N_FFT))
     g = torch.Generator().manual_seed(1)
     fr = (0.1 * torch.randn(BATCH, N_FFT, generator=g)).to(dev)
-    kt = staged_kernel_times(dnb, fr, dnb.init_hx(BATCH), 200)
+    kt = staged_kernel_times(dnb, fr, dnb.init_hx(BATCH), 300)
     conv = CONV_FLOP_PER_FRAME * BATCH / (kt["cell"] * 1e-3) / 1e12
     res["config3_bf16"] = {"value": round(v, 1), "unit": "frames/s", "ms_per_step": round(ms, 4), "streams": BATCH,
                            "pipeline_depth": default_depth(BATCH, N_FFT), "cell_ms": round(kt["cell"], 4),
@@ -166,9 +174,7 @@ def extra_measurements(args, dev, budget_steps=1500):
     hop = (0.1 * torch.randn(B5, dn.hop, generator=g)).to(dev)
     hop_out = torch.empty_like(hop)
     graph = ps.graph_step(hop, hop_out)
-    for _ in range(20):
-        graph.replay()
-    torch.cuda.synchronize()
+    prewarm(graph.replay)
     n5 = 400
     t0 = time.perf_counter()
     for _ in range(n5):

@@ -16,7 +16,7 @@ from audio_denoising_amd.pipeline import HopPipeline  # noqa: E402
 
 B, depth = int(sys.argv[1]), int(sys.argv[2])
 dev = torch.device("cuda", 0)
-dn = bench.build_denoiser(dev)
+dn = bench.build_denoiser(dev, "S", os.environ.get("DN_CONV", "fp32"))
 if len(sys.argv) > 3:
     dn.n_iter = int(sys.argv[3])
 frames = (0.1 * torch.randn(B, dn.n_fft)).to(dev)
