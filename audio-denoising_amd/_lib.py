@@ -25,7 +25,7 @@ SYMBOLS = (
     "dn_dsp_get_tables", "dn_stft", "dn_stft_mel_log1p", "dn_mel_scale", "dn_invmel", "dn_residual_invmel",
     "dn_griffinlim", "dn_griffinlim_draw_phases", "dn_synthesis", "dn_istft", "dn_workspace_bytes", "dn_process_frame", "dn_stream_step",
     "dn_pipe_create", "dn_pipe_destroy", "dn_pipe_set_model", "dn_pipe_set_head_start", "dn_pipe_set_gl_schedule", "dn_pipe_set_depth", "dn_pipe_reserve_parity", "dn_pipe_get_counters", "dn_pipe_submit", "dn_pipe_flush", "dn_pipe_stream_create", "dn_pipe_stream_push",
-    "dn_pipe_stream_flush", "dn_pipe_stream_get_state", "dn_pipe_stream_set_state", "dn_momo_create", "dn_momo_destroy",
+    "dn_pipe_stream_flush", "dn_pipe_stream_push_host", "dn_pipe_stream_host_wait", "dn_pipe_stream_get_state", "dn_pipe_stream_set_state", "dn_momo_create", "dn_momo_destroy",
     "dn_momo_forward", "dn_last_error", "dn_abi_version",
 )
 
@@ -33,6 +33,7 @@ DN_PEAK_NORMALIZE = 1
 DN_PRE_WINDOW = 2
 DN_CONV_BF16 = 1
 DN_GL_AUTO, DN_GL_WAVE_PER_COLUMN, DN_GL_WAVE_PER_STREAM = 0, 1, 2
+DN_HOST_STAGED = 1
 ABI_VERSION = 3
 
 
@@ -114,6 +115,8 @@ class DnLib:
         L.dn_pipe_stream_create.argtypes = [vp, vp, i32, u32, C.POINTER(vp)]
         L.dn_pipe_stream_push.argtypes = [vp, p, i32, p, i32, p, u64, u64, i32, f32, vp]
         L.dn_pipe_stream_flush.argtypes = [vp, p, i32, i32, f32, vp]
+        L.dn_pipe_stream_push_host.argtypes = [vp, p, i32, p, i32, u64, u64, i32, f32, u32, vp, C.POINTER(u64)]
+        L.dn_pipe_stream_host_wait.argtypes = [vp, u64]
         L.dn_pipe_stream_get_state.argtypes = [vp, p, p, p, vp]
         L.dn_pipe_stream_set_state.argtypes = [vp, p, p, p, u64, vp]
         if L.dn_abi_version() != ABI_VERSION:

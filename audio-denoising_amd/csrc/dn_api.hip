@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include <atomic>
+#include <thread>
 #include <map>
 #include <mutex>
 #include <string>
@@ -133,7 +134,24 @@ struct dn_dsp {
     std::vector<float> fb, pinv, window;   // host copies [K][M], [K][M], [N]
 };
 
+// host-buffer transport of a streaming pipe (dn_pipe_stream_push_host): two copy queues beside the caller's compute stream, device staging
+// double-buffered, everything ordered by events on the device -- the host never blocks inside a push
+struct HostIo {
+    hipStream_t h2d = nullptr, d2h = nullptr;
+    static constexpr int kRing = 4;           // pushes whose events are kept (the host may run this far ahead of the result it waits for)
+    hipEvent_t ev_h2d[kRing] = {}, ev_k[kRing] = {}, ev_d2h[kRing] = {};
+    void* d_in[2] = {nullptr, nullptr};
+    void* d_out[2] = {nullptr, nullptr};
+    unsigned long long pushes = 0;
+    // zero copy: the launch itself publishes "push n is in host memory" in this page-locked word (no HIP event, no barrier packet between hops)
+    unsigned long long* done_host = nullptr;
+    unsigned long long* done_dev = nullptr;
+    unsigned long long zero_copy_pushes = 0;       // pushes whose completion is published there (the others: ev_d2h)
+    bool last_zero_copy[kRing] = {};
+};
+
 struct dn_pipe {
+    HostIo* hio = nullptr;
     dn_model* m = nullptr;
     dn_dsp* d = nullptr;
     int B = 0, C = 0;
@@ -150,6 +168,8 @@ struct dn_pipe {
     BiasSet* bs = nullptr;
     bool submitted = false;                   // frame mode: a hop may be pending (its destination travels in the slot, not here)
     // streaming mode: per-stream state owned by the pipe
+    unsigned long long* host_done = nullptr;  // set around a zero-copy host push (dn_pipe_stream_push_host)
+    unsigned long long host_done_value = 0;
     float* ring = nullptr;                    // [B][n_fft] last n_fft input samples
     float* ola = nullptr;                     // [B][n_fft] output overlap-add line
     float* hx = nullptr;                      // [B][17][C]
@@ -844,6 +864,24 @@ int dn_pipe_create(const dn_model* m, const dn_dsp* d, int32_t B, uint32_t flags
 
 void dn_pipe_destroy(dn_pipe* p) {
     if (!p) return;
+    if (p->hio) {
+        HostIo* h = p->hio;
+        if (h->h2d) (void)hipStreamSynchronize(h->h2d);
+        if (h->d2h) (void)hipStreamSynchronize(h->d2h);
+        for (int i = 0; i < HostIo::kRing; ++i) {
+            if (h->ev_h2d[i]) (void)hipEventDestroy(h->ev_h2d[i]);
+            if (h->ev_k[i]) (void)hipEventDestroy(h->ev_k[i]);
+            if (h->ev_d2h[i]) (void)hipEventDestroy(h->ev_d2h[i]);
+        }
+        for (int i = 0; i < 2; ++i) {
+            if (h->d_in[i]) (void)hipFree(h->d_in[i]);
+            if (h->d_out[i]) (void)hipFree(h->d_out[i]);
+        }
+        if (h->h2d) (void)hipStreamDestroy(h->h2d);
+        if (h->d2h) (void)hipStreamDestroy(h->d2h);
+        if (h->done_host) (void)hipHostFree(h->done_host);
+        delete h;
+    }
     if (p->scratch) (void)hipFree(p->scratch);
     if (p->scratch_init) (void)hipFree(p->scratch_init);
     if (p->gl_state) (void)hipFree(p->gl_state);
@@ -1015,10 +1053,116 @@ int dn_pipe_stream_push(dn_pipe* p, const void* hop_in, int32_t in_is_s16, void*
     int rc = fill_hop_args(p, a, init_angles, seed, stream_id0, n_iter, momentum);
     if (rc != DN_OK) return rc;
     a.front_B = p->B; a.hx = p->hx;
+    a.host_done = p->host_done; a.host_done_value = p->host_done_value;
     a.hop_in = hop_in; a.ring = p->ring; a.in_s16 = in_is_s16;
     a.ola = p->ola; a.hop_out = hop_out; a.out_s16 = out_is_s16;
     dn::launch_hop(p->d->view, p->bs->view, a, p->bf16, as_stream(stream));
     return check_launch("hop_kernel(stream)");
+}
+
+// ---- host-buffer transport (app3.py:168-172,189,215,244-250: the reference crosses host <-> device every hop)
+static int host_io_init(dn_pipe* p) {
+    if (p->hio) return DN_OK;
+    HostIo* h = new HostIo();
+    p->hio = h;                       // (dn_pipe_destroy releases whatever was created)
+    const size_t bytes = (size_t)p->B * p->d->cfg.hop * sizeof(float);
+    DN_HIP(hipStreamCreateWithFlags(&h->h2d, hipStreamNonBlocking));
+    DN_HIP(hipStreamCreateWithFlags(&h->d2h, hipStreamNonBlocking));
+    for (int i = 0; i < HostIo::kRing; ++i) {
+        DN_HIP(hipEventCreateWithFlags(&h->ev_h2d[i], hipEventDisableTiming));
+        DN_HIP(hipEventCreateWithFlags(&h->ev_k[i], hipEventDisableTiming));
+        DN_HIP(hipEventCreateWithFlags(&h->ev_d2h[i], hipEventDisableTiming));
+    }
+    for (int i = 0; i < 2; ++i) {
+        DN_HIP(hipMalloc(&h->d_in[i], bytes));
+        DN_HIP(hipMalloc(&h->d_out[i], bytes));
+    }
+    DN_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->done_host), 64, 0));
+    *h->done_host = 0;
+    void* dv = nullptr;
+    DN_HIP(hipHostGetDevicePointer(&dv, h->done_host, 0));
+    h->done_dev = static_cast<unsigned long long*>(dv);
+    return DN_OK;
+}
+
+// the device's own address of page-locked host memory, or null when `host` is pageable
+static void* device_view(const void* host) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, host) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (at.type != hipMemoryTypeHost) return nullptr;
+    void* dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, const_cast<void*>(host), 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return dp;
+}
+
+int dn_pipe_stream_push_host(dn_pipe* p, const void* hop_in_host, int32_t in_is_s16, void* hop_out_host, int32_t out_is_s16, uint64_t seed,
+                             uint64_t stream_id0, int32_t n_iter, float momentum, uint32_t flags, void* stream, uint64_t* ticket) {
+    if (!p || !p->ring) return fail(DN_ERR_INVALID, "dn_pipe_stream_push_host: not a streaming pipe");
+    if (!hop_in_host || !hop_out_host) return fail(DN_ERR_INVALID, "dn_pipe_stream_push_host: null argument");
+    if (flags & ~(uint32_t)DN_HOST_STAGED) return fail(DN_ERR_INVALID, "dn_pipe_stream_push_host: unknown flag bits");
+    int rc = host_io_init(p);
+    if (rc != DN_OK) return rc;
+    HostIo* h = p->hio;
+    hipStream_t cs = as_stream(stream);
+    if (!(flags & DN_HOST_STAGED)) {
+        // zero copy: page-locked host memory is in the device's address space.  The front workgroups read their stream's hop (1 KB) straight from it
+        // and the Griffin-Lim workgroups store the emitted hop straight into it -- no copy engine, no second queue, no cross-queue event.
+        void* din = device_view(hop_in_host);
+        void* dout = device_view(hop_out_host);
+        if (din && dout) {
+            p->host_done = h->done_dev;                         // picked up by the launch below: its last workgroup stores pushes + 1 there
+            p->host_done_value = h->pushes + 1;
+            rc = dn_pipe_stream_push(p, din, in_is_s16, dout, out_is_s16, nullptr, seed, stream_id0, n_iter, momentum, stream);
+            p->host_done = nullptr;
+            if (rc != DN_OK) return rc;
+            h->last_zero_copy[h->pushes % HostIo::kRing] = true;
+            if (ticket) *ticket = h->pushes;
+            ++h->pushes;
+            return DN_OK;
+        }
+    }
+    const int s = (int)(h->pushes & 1);                                  // device staging buffer
+    const int e = (int)(h->pushes % HostIo::kRing), e2 = (int)((h->pushes + HostIo::kRing - 2) % HostIo::kRing);      // this push's events; those of two pushes ago
+    const size_t n = (size_t)p->B * p->d->cfg.hop;
+    const size_t bin = n * (in_is_s16 ? sizeof(short) : sizeof(float)), bout = n * (out_is_s16 ? sizeof(short) : sizeof(float));
+    h->last_zero_copy[h->pushes % HostIo::kRing] = false;
+    // upload: the staging buffer was read by the launch two pushes ago
+    if (h->pushes >= 2) DN_HIP(hipStreamWaitEvent(h->h2d, h->ev_k[e2], 0));
+    DN_HIP(hipMemcpyAsync(h->d_in[s], hop_in_host, bin, hipMemcpyHostToDevice, h->h2d));
+    DN_HIP(hipEventRecord(h->ev_h2d[e], h->h2d));
+    // the hop: after its samples arrived, and after the download of the result it is about to overwrite
+    DN_HIP(hipStreamWaitEvent(cs, h->ev_h2d[e], 0));
+    if (h->pushes >= 2) DN_HIP(hipStreamWaitEvent(cs, h->ev_d2h[e2], 0));
+    rc = dn_pipe_stream_push(p, h->d_in[s], in_is_s16, h->d_out[s], out_is_s16, nullptr, seed, stream_id0, n_iter, momentum, stream);
+    if (rc != DN_OK) return rc;
+    DN_HIP(hipEventRecord(h->ev_k[e], cs));
+    // download
+    DN_HIP(hipStreamWaitEvent(h->d2h, h->ev_k[e], 0));
+    DN_HIP(hipMemcpyAsync(hop_out_host, h->d_out[s], bout, hipMemcpyDeviceToHost, h->d2h));
+    DN_HIP(hipEventRecord(h->ev_d2h[e], h->d2h));
+    if (ticket) *ticket = h->pushes;
+    ++h->pushes;
+    return DN_OK;
+}
+
+int dn_pipe_stream_host_wait(dn_pipe* p, uint64_t ticket) {
+    if (!p || !p->hio) return fail(DN_ERR_INVALID, "dn_pipe_stream_host_wait: no host push was made on this pipe");
+    HostIo* h = p->hio;
+    if (ticket >= h->pushes) return fail(DN_ERR_INVALID, "dn_pipe_stream_host_wait: no such push");
+    // the last kRing pushes still own their events; the download queue is in order, so for an older push the oldest event still alive will do
+    const uint64_t oldest = h->pushes > (uint64_t)HostIo::kRing ? h->pushes - HostIo::kRing : 0;
+    const uint64_t e = ticket > oldest ? ticket : oldest;
+    if (h->last_zero_copy[e % HostIo::kRing]) {
+        // launches of one stream complete in order: the word only grows.  Spin briefly, then yield (a hop is tens of microseconds)
+        const volatile unsigned long long* w = h->done_host;
+        for (unsigned spins = 0; __atomic_load_n(w, __ATOMIC_ACQUIRE) < e + 1; ++spins) {
+            if (spins > 2000) std::this_thread::yield();
+            if ((spins & 0xffff) == 0xffff && hipGetLastError() != hipSuccess) return fail(DN_ERR_HIP, "dn_pipe_stream_host_wait: the device reported an error");
+        }
+        return DN_OK;
+    }
+    DN_HIP(hipEventSynchronize(h->ev_d2h[e % HostIo::kRing]));
+    return DN_OK;
 }
 
 int dn_pipe_stream_flush(dn_pipe* p, void* hop_out, int32_t out_is_s16, int32_t n_iter, float momentum, void* stream) {

@@ -340,8 +340,9 @@ __device__ __forceinline__ void glw_body(char* smem, const DspDev& d, const floa
             const int n = 2 * (lane + 64 * t);
             if (out_s16) {
                 const float c0 = fminf(fmaxf(cur[t][0], -1.0f), 1.0f) * 32767.0f, c1 = fminf(fmaxf(cur[t][1], -1.0f), 1.0f) * 32767.0f;   // np.clip, * iinfo(int16).max
-                short* q = static_cast<short*>(hop_out) + b * (kNR / 2) + n;
-                q[0] = (short)c0; q[1] = (short)c1;                                                                                         // astype(int16): truncation
+                // astype(int16): truncation; the pair goes out as ONE 4-byte store (the buffer may be host memory behind PCIe)
+                const unsigned int pair = (unsigned int)(unsigned short)(short)c0 | ((unsigned int)(unsigned short)(short)c1 << 16);
+                *reinterpret_cast<unsigned int*>(static_cast<short*>(hop_out) + b * (kNR / 2) + n) = pair;
             } else {
                 *reinterpret_cast<v2f*>(static_cast<float*>(hop_out) + b * (kNR / 2) + n) = cur[t];
             }

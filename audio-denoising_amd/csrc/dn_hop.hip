@@ -291,6 +291,8 @@ __global__ __launch_bounds__(kHopPipeThreads, (NFFT == 1536 || GLW) ? 2 : 1) voi
     // ---- ticket: the last workgroup of the launch advances the control block (every workgroup has read it by then)
     __syncthreads();
     if (tid == 0) {
+        // (zero-copy host transport: this workgroup's stores to host memory are uncached writes that every wave waited out (vmcnt) at the barrier
+        // above; they are posted ahead of whatever the last workgroup publishes after the ticket below -- no L2 write-back per workgroup)
         const unsigned int t = atomicAdd(&a.ctl->done, 1u);
         if (t == gridDim.x - 1) {
             a.ctl->done = 0;
@@ -303,6 +305,10 @@ __global__ __launch_bounds__(kHopPipeThreads, (NFFT == 1536 || GLW) ? 2 : 1) voi
                 a.ctl->slot_next = (int)slot_next + 1 == a.n_slots ? 0u : slot_next + 1;
             }
             a.ctl->pending = pending - (completes ? 1u : 0u) + (fronted ? 1u : 0u);
+            if (a.host_done != nullptr) {
+                __threadfence_system();
+                __hip_atomic_store(a.host_done, a.host_done_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
     }
 }

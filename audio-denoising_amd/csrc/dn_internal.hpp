@@ -160,6 +160,9 @@ struct HopArgs {
     // as its frame (app3.py:178,226); the back half folds its frame into `ola` and emits `hop_out` (app3.py:219-224)
     const void* hop_in; float* ring; int in_s16; int prime;
     float* ola; void* hop_out; int out_s16;
+    // zero-copy host transport: hop_in / hop_out are page-locked HOST memory; the last workgroup of the launch, after every workgroup's stores have
+    // been fenced to system scope, publishes host_done_value in *host_done (page-locked too) -- the host polls that word instead of a HIP event
+    unsigned long long* host_done; unsigned long long host_done_value;
 };
 void launch_hop(const DspDev& d, const CellDev& c, const HopArgs& a, bool bf16, hipStream_t st);
 void launch_ctl_set(PipeCtl* ctl, unsigned long long pushes, unsigned long long frames, unsigned int pending, hipStream_t st);

@@ -348,6 +348,64 @@ class PipelinedStream(_Pipe):
             self.lib.check(self.lib.dn_pipe_stream_set_state(self.handle, ring.data_ptr(), ola.data_ptr(), hx.data_ptr(), int(frames), st))
 
 
+class HostFedStream(PipelinedStream):
+    """``PipelinedStream`` fed from HOST buffers, as the reference feeds its hop (int16 frames on the host, ``.to(device)`` / ``.cpu()`` around
+    the model: app3.py:168-172,189,215,244-250) -- with the transfers overlapped: ``dn_pipe_stream_push_host`` uploads hop i+1 and downloads
+    the result of hop i-1 on two copy queues while hop i computes (device staging double-buffered; page-locked rings of four buffers here).
+    ``push(hop)`` takes a CPU tensor ``(B, hop_length)`` (int16 or float32) and returns the samples emitted ``LAG`` = 2 pushes earlier (zeros
+    until then): the host stays two pushes ahead of the GPU, so it never waits for a hop that is still computing and the GPU never waits
+    for the host.  ``drain()`` returns what is still on its way.  Same samples as the device-fed stream, bit for bit."""
+
+    LAG = 2
+    RING = 4
+
+    def __init__(self, denoiser: "Denoiser", batch: int, stream_id0: int = 0, seed: int = 0, s16: bool = True, depth: int = 1,
+                 staged: bool = False):
+        super().__init__(denoiser, batch, stream_id0, seed)
+        if depth != 1:
+            self.set_depth(depth)
+        self._hflags = _lib.DN_HOST_STAGED if staged else 0    # default: zero copy (the launch reads / writes the page-locked buffers itself)
+        dt = torch.int16 if s16 else torch.float32
+        self._pin_in = [torch.zeros(batch, denoiser.hop, dtype=dt).pin_memory() for _ in range(self.RING)]
+        self._pin_out = [torch.zeros(batch, denoiser.hop, dtype=dt).pin_memory() for _ in range(self.RING)]
+        self._in_ptr = [t.data_ptr() for t in self._pin_in]
+        self._out_ptr = [t.data_ptr() for t in self._pin_out]
+        self._nbytes = self._pin_in[0].numel() * self._pin_in[0].element_size()
+        self._dtype = dt
+        self._s16 = int(s16)
+        self._n = 0                # pushes made
+        self._taken = 0            # results handed out
+        self._ticket = C.c_uint64()
+
+    def push(self, hop: torch.Tensor, copy: bool = True) -> torch.Tensor:
+        d = self.dn
+        if hop.dtype != self._dtype or hop.device.type != "cpu" or tuple(hop.shape) != (self.batch, d.hop) or not hop.is_contiguous():
+            raise ValueError(f"hop must be a contiguous CPU tensor {self._dtype} of shape {(self.batch, d.hop)}")
+        k = self._n % self.RING
+        # ring slot k was last used by push n - RING: its upload finished before the result of push n - RING was handed out, LAG pushes ago
+        C.memmove(self._in_ptr[k], hop.data_ptr(), self._nbytes)
+        with torch.cuda.device(d.device):
+            st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            self.lib.check(self.lib.dn_pipe_stream_push_host(self.handle, self._in_ptr[k], self._s16, self._out_ptr[k], self._s16,
+                                                             self.seed, self.stream_id0, d.n_iter, d.momentum, self._hflags, st, C.byref(self._ticket)))
+        self._n += 1
+        if self._n <= self.LAG:
+            return torch.zeros_like(self._pin_out[0])
+        return self._result(self._n - 1 - self.LAG, copy)
+
+    def _result(self, i: int, copy: bool) -> torch.Tensor:
+        self.lib.check(self.lib.dn_pipe_stream_host_wait(self.handle, i))
+        self._taken = i + 1
+        out = self._pin_out[i % self.RING]
+        return out.clone() if copy else out
+
+    def drain(self) -> torch.Tensor:
+        """The results of the pushes not handed out yet, then the hops still in flight in the pipe (``flush``), on the host."""
+        parts = [self._result(i, True) for i in range(self._taken, self._n)]
+        tail = self.flush(s16=bool(self._s16)).cpu()
+        return torch.cat(parts + [tail], dim=1)
+
+
 class DenoiserStream:
     """B concurrent streams with persistent device state: input ring, output overlap-add buffer, hx.
 

@@ -290,7 +290,19 @@ def side_measurement(args, dn, B, dev):
     out = torch.empty(B, dn.n_fft, device=dev)
     hx = dn.init_hx(B)
     mode = "frames"
-    if args.stream:
+    if args.stream and args.pcie:
+        # the host-buffer transport of the streaming form (dn_pipe_stream_push_host): int16 hops in page-locked host memory, upload / hop / download
+        # on three queues, double-buffered -- beside the same stream fed from device memory
+        from audio_denoising_amd.pipeline import HostFedStream
+        staged = os.environ.get("DN_HOST_STAGED") == "1"
+        hs = HostFedStream(dn, B, s16=True, depth=args.depth if args.depth > 0 else 1, staged=staged)
+        hop_h = (0.1 * torch.randn(B, dn.hop, generator=g) * 32767.0).to(torch.int16)
+        mode = f"stream+pcie (int16 hops in pinned host memory, {'staged copies on two queues' if staged else 'zero copy'}), depth {hs.depth}"
+
+        def step(i):
+            hs.push(hop_h, copy=False)
+        fin = hs.drain
+    elif args.stream:
         ps = PipelinedStream(dn, B)
         if args.depth > 0:
             ps.set_depth(args.depth)

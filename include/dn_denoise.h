@@ -308,6 +308,22 @@ int dn_pipe_stream_push(dn_pipe* p, const void* hop_in, int32_t in_is_s16, void*
                         const float* init_angles, uint64_t seed, uint64_t stream_id0, int32_t n_iter, float momentum,
                         void* stream);
 int dn_pipe_stream_flush(dn_pipe* p, void* hop_out, int32_t out_is_s16, int32_t n_iter, float momentum, void* stream);
+/* Host-buffer transport of the streaming form: the reference hands every hop across the host/device boundary (frames arrive as int16 arrays on
+ * the host, app3.py:168-172; x.to(device) / y.cpu() around the hop, app3.py:189,215; int16 out, app3.py:244-250).  hop_in_host / hop_out_host
+ * [host][B][hop] (int16 or float32).  The call enqueues on `stream` and returns without waiting.
+ *   Page-locked buffers (hipHostMalloc, hipHostRegister, torch pin_memory): ZERO COPY -- the launch reads each stream's hop (1 KB) straight from
+ *   host memory and stores the emitted hop straight into it; no copy engine and no second queue are involved.
+ *   Pageable buffers, or flags = DN_HOST_STAGED: an upload on a copy queue of the pipe, the hop on `stream` behind it, a download on a second copy
+ *   queue; device staging is double-buffered, so the upload of hop i+1 and the download of hop i-1 run while hop i computes.
+ * `*ticket` (may be NULL) names the push: dn_pipe_stream_host_wait(p, ticket) blocks the calling thread until that push's samples are in ITS
+ * hop_out_host.  hop_in_host must stay unchanged, and hop_out_host untouched, until then (wait for push i before reusing the buffers of push i;
+ * with four sets in rotation the host can stay two pushes ahead of the result it waits for, which keeps the GPU busy back to back).  Initial phases
+ * come from the device generator; mix freely with dn_pipe_stream_push / _flush on the same `stream`. */
+#define DN_HOST_STAGED 1u
+int dn_pipe_stream_push_host(dn_pipe* p, const void* hop_in_host, int32_t in_is_s16, void* hop_out_host, int32_t out_is_s16,
+                             uint64_t seed, uint64_t stream_id0, int32_t n_iter, float momentum, uint32_t flags, void* stream,
+                             uint64_t* ticket);
+int dn_pipe_stream_host_wait(dn_pipe* p, uint64_t ticket);
 /* Checkpoint / resume of live streams: copy the pipe-owned state out to / in from caller buffers [dev]
  * (ring [B][n_fft], ola [B][n_fft], hx [B][17][C]; any may be NULL), ordered on `stream`.  Take snapshots after
  * dn_pipe_stream_flush: set_state drops a pending hop.  A restored ring counts as primed; frames_done (the `frames`

@@ -63,6 +63,18 @@ inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return
 inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return 0; }
 inline hipError_t hipEventDestroy(hipEvent_t) { return 0; }
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
+// pointer attributes: everything is "host pageable" here, so the staged path of dn_pipe_stream_push_host is what the emulation runs
+enum hipMemoryType { hipMemoryTypeHost, hipMemoryTypeDevice, hipMemoryTypeUnregistered };
+struct hipPointerAttribute_t { hipMemoryType type; };
+inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void*) { a->type = hipMemoryTypeUnregistered; return 0; }
+inline hipError_t hipHostGetDevicePointer(void** d, void* h, unsigned) { *d = h; return 0; }
+inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = malloc(n); return *p ? 0 : 1; }
+inline hipError_t hipHostFree(void* p) { free(p); return 0; }
+// system-scope fence / store: the emulation is one process, sequentially consistent atomics will do
+inline void __threadfence_system() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+#define __HIP_MEMORY_SCOPE_SYSTEM 5
+template <typename T> inline void __hip_atomic_store(T* p, T v, int, int) { __atomic_store_n(p, v, __ATOMIC_SEQ_CST); }
 inline const char* hipGetErrorString(hipError_t) { return "emulated"; }
 
 namespace dn_emu {
