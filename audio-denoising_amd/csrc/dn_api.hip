@@ -909,7 +909,8 @@ int dn_pipe_set_head_start(dn_pipe* p, int32_t iterations) {
 int dn_pipe_set_depth(dn_pipe* p, int32_t depth) {
     if (!p) return fail(DN_ERR_INVALID, "dn_pipe_set_depth: null pipe");
     if (depth < 1 || depth > DN_PIPE_MAX_DEPTH) return fail(DN_ERR_INVALID, "dn_pipe_set_depth: depth must be in 1.." + std::to_string(DN_PIPE_MAX_DEPTH));
-    if (depth > 1 && p->d->cfg.n_fft != 1024) return fail(DN_ERR_UNSUPPORTED, "pipes deeper than one hop are built for n_fft 1024");
+    if (depth > 1 && p->d->cfg.n_fft != 1024)
+        return fail(DN_ERR_UNSUPPORTED, "pipes deeper than one hop are built for n_fft 1024 (at 1536 the per-lane state of a stream does not fit a wavefront's registers)");
     if (depth == p->depth) return DN_OK;
     // nothing may be in flight: the slots are re-laid out
     dn::PipeCtl h{};
@@ -929,6 +930,10 @@ int dn_pipe_set_depth(dn_pipe* p, int32_t depth) {
     if (p->scratch_init) (void)hipFree(p->scratch_init);
     p->scratch = scratch; p->gl_state = state; p->scratch_init = nullptr;
     p->depth = depth; p->n_slots = n_slots;
+    if (depth > 1) {          // a deep pipe's front workgroups leave every frame's initial phases in its slot (dn_hop.hip)
+        int rc = dn_pipe_reserve_parity(p);
+        if (rc != DN_OK) return rc;
+    }
     if (depth > 1) p->gl_split = 0;             // the chain is cut into segments instead
     h.slot_next = 0;
     DN_HIP(hipMemcpy(p->ctl, &h, sizeof(h), hipMemcpyHostToDevice));
@@ -940,7 +945,7 @@ int dn_pipe_set_gl_schedule(dn_pipe* p, int32_t schedule) {
     if (schedule != DN_GL_AUTO && schedule != DN_GL_WAVE_PER_COLUMN && schedule != DN_GL_WAVE_PER_STREAM)
         return fail(DN_ERR_INVALID, "dn_pipe_set_gl_schedule: unknown schedule");
     if (schedule == DN_GL_WAVE_PER_STREAM && p->d->cfg.n_fft != 1024)
-        return fail(DN_ERR_UNSUPPORTED, "the wavefront-per-stream Griffin-Lim is built for n_fft 1024");
+        return fail(DN_ERR_UNSUPPORTED, "the wavefront-per-stream Griffin-Lim is built for n_fft 1024 (at 1536 the per-lane state of a stream does not fit a wavefront's registers)");
     if (schedule == DN_GL_WAVE_PER_COLUMN && p->depth > 1)
         return fail(DN_ERR_INVALID, "a pipe deeper than one hop runs a wavefront per stream and chain segment");
     p->gl_schedule = schedule;

@@ -18,7 +18,11 @@
 
 namespace dn {
 
-constexpr int kGlwStreams = 4;        // streams (= wavefronts) per workgroup
+// n_fft 1024 only.  At 1536 (12 values a lane) the per-lane state of three columns -- 78 registers of previous spectra, 39 magnitudes, the old and the
+// new signal, one transform -- does not fit the 256 registers of a wave that shares its SIMD: built and measured in round 3 (columns one after the other,
+// radix-12 twiddles in LDS, three streams a workgroup): 360-400 B of scratch a lane, 46 scratch accesses in every iteration, and 1.6x SLOWER than a
+// wavefront per column at 1,024 streams (662 against 410 us per hop), 1.7-2.3x slower as a deep pipe at 256.  Removed again; gl_body serves n_fft 1536.
+constexpr int kGlwWaves = 4;          // wavefronts of a workgroup that run a chain (streams x chain segments)
 
 #ifdef DN_PROBE
 // diagnostic build only: s_memtime stamps of the four wavefronts of workgroup 0 (tools/glw_probe.py)
@@ -36,7 +40,7 @@ template <int NFFT> struct GlwLds {
     static constexpr int kWsyn = kCw + 8 * 3 * G::kNC;                  // v2f [NC]     synthesis window / NC
     static constexpr int kWave = kWsyn + 8 * G::kNC;                    // per wavefront: two exchange tiles, the rebuilt signal
     static constexpr int kPerWave = 8 * 2 * G::kTile + 4 * NFFT;
-    static constexpr int kTotal = kWave + kGlwStreams * kPerWave;
+    static constexpr int kTotal = kWave + kGlwWaves * kPerWave;
 };
 template <int NFFT> constexpr int glw_smem() { return GlwLds<NFFT>::kTotal; }
 
@@ -78,11 +82,11 @@ __device__ __forceinline__ void glw_body(char* smem, const DspDev& d, const floa
                                          int it_begin, int it_stop, int resume, v2f* __restrict__ state) {
     using G = Geo<NFFT>;
     using L = GlwLds<NFFT>;
-    static_assert(NFFT == 1024, "one wavefront per stream is built for n_fft 1024");
     constexpr int kNR = G::kNR, kNC = G::kNC, kHop = G::kHop, kBins = G::kBins, kNV = G::kNV, kNP = G::kNP, kTile = G::kTile;
     constexpr int kHalf = kNV / 2;                       // registers between a sample pair and the one a hop further
     const v2f* cw_t = reinterpret_cast<const v2f*>(smem + L::kCw);
     const v2f* wsyn_t = reinterpret_cast<const v2f*>(smem + L::kWsyn);
+    static_assert(NFFT == 1024, "one wavefront per stream is built for n_fft 1024 (see above)");
     char* mine = smem + L::kWave + wv * L::kPerWave;
     v2f* tile0 = reinterpret_cast<v2f*>(mine);
     v2f* tile1 = tile0 + kTile;
@@ -105,42 +109,63 @@ __device__ __forceinline__ void glw_body(char* smem, const DspDev& d, const floa
         const float inv = __builtin_amdgcn_rsqf(fmaf(a[0], a[0], fmaf(a[1], a[1], 1e-32f)));
         x = a * (inv * m);
     };
-    // istft of the side columns (0, 2) as a pair, then the centre column, from X = angles * magnitude; leaves the overlap-add in snew
+    // one or two transforms of this wave in lock step (tile0, tile1)
+    auto fft = [&](auto inv, auto& v) {
+        constexpr bool INV = decltype(inv)::value;
+        constexpr int N = sizeof(v) / sizeof(v[0]);
+        v2f* const tiles[2] = {tile0, tile1};
+        if constexpr (N == 2) G::Fft::template run_n<INV, 2>(v, tw, tiles, lane);
+        else {
+            v2f* const one[1] = {tile0};
+            G::Fft::template run_n<INV, 1>(v, tw, one, lane);
+        }
+    };
+    // istft from X = angles * magnitude, into the overlap-add `acc` (the NEXT rebuilt signal): first the side columns (0 and 2, as a pair of
+    // transforms) -- column 0 keeps its second half -> s[n - H], column 2 its first half -> s[n + H], the other halves fall
+    // outside the istft trim -- then the centre column on top: (centre + side) of rounded products, as gl_body
+    using XP = v2f[kNP];
+    auto synth_side = [&](XP& x0lo, XP& x0hi, v2f x0mid, XP& x2lo, XP& x2hi, v2f x2mid, v2f (&acc)[kNV]) {
+        v2f v[2][kNV];
+        irfft_merge_pairs<kNV>(x0lo, x0hi, x0mid, wkh, lane, v[0]);
+        irfft_merge_pairs<kNV>(x2lo, x2hi, x2mid, wkh, lane, v[1]);
+        fft(std::true_type{}, v);
+#pragma unroll
+        for (int t = 0; t < kHalf; ++t) {
+            acc[t] = cmul_elem(v[0][t + kHalf], wsyn_t[lane + 64 * (t + kHalf)]);
+            acc[t + kHalf] = cmul_elem(v[1][t], wsyn_t[lane + 64 * t]);
+        }
+    };
+    auto synth_centre = [&](XP& x1lo, XP& x1hi, v2f x1mid, v2f (&acc)[kNV]) {
+        v2f v[1][kNV];
+        irfft_merge_pairs<kNV>(x1lo, x1hi, x1mid, wkh, lane, v[0]);
+        fft(std::true_type{}, v);
+#pragma unroll
+        for (int t = 0; t < kNV; ++t) acc[t] = cadd(cmul_elem(v[0][t], wsyn_t[lane + 64 * t]), acc[t]);
+    };
+    // the new signal becomes THE signal: registers, and the wave's LDS line for the reflected half columns of the next analysis (this wave's LDS
+    // operations execute in order)
+    auto publish = [&](const v2f (&acc)[kNV]) {
+        wave_sync();
+#pragma unroll
+        for (int t = 0; t < kNV; ++t) {
+            snew[t] = acc[t];
+            *reinterpret_cast<v2f*>(sl + 2 * (lane + 64 * t)) = acc[t];
+        }
+        wave_sync();
+    };
     auto synthesize = [&](v2f (&xlo)[3][kNP], v2f (&xhi)[3][kNP], v2f (&xmid)[3]) {
-        {
-            v2f v[2][kNV];
-            irfft_merge_pairs<kNV>(xlo[0], xhi[0], xmid[0], wkh, lane, v[0]);
-            irfft_merge_pairs<kNV>(xlo[2], xhi[2], xmid[2], wkh, lane, v[1]);
-            v2f* const tiles[2] = {tile0, tile1};
-            G::Fft::template run_n<true, 2>(v, tw, tiles, lane);
-            // column 0 keeps its second half -> s[n - H]; column 2 its first half -> s[n + H] (the other halves fall outside the istft trim)
-#pragma unroll
-            for (int t = 0; t < kHalf; ++t) {
-                snew[t] = cmul_elem(v[0][t + kHalf], wsyn_t[lane + 64 * (t + kHalf)]);
-                snew[t + kHalf] = cmul_elem(v[1][t], wsyn_t[lane + 64 * t]);
-            }
-        }
-        {
-            v2f v[1][kNV];
-            irfft_merge_pairs<kNV>(xlo[1], xhi[1], xmid[1], wkh, lane, v[0]);
-            v2f* const tiles[1] = {tile0};
-            G::Fft::template run_n<true, 1>(v, tw, tiles, lane);
-#pragma unroll
-            for (int t = 0; t < kNV; ++t) snew[t] = cadd(cmul_elem(v[0][t], wsyn_t[lane + 64 * t]), snew[t]);       // (centre + side) of rounded products, as gl_body
-        }
-        // the reflected half columns of the next analysis read the line; this wave's LDS operations execute in order
-        wave_sync();
-#pragma unroll
-        for (int t = 0; t < kNV; ++t) *reinterpret_cast<v2f*>(sl + 2 * (lane + 64 * t)) = snew[t];
-        wave_sync();
+        v2f acc[kNV];
+        synth_side(xlo[0], xhi[0], xmid[0], xlo[2], xhi[2], xmid[2], acc);
+        synth_centre(xlo[1], xhi[1], xmid[1], acc);
+        publish(acc);
     };
 
     const bool park = it_stop >= 0;
     const int it_last = park ? it_stop : n_iter;
-    // segment format: per stream 19 rows of 64 lanes -- rows 0..11: float4 (plo pairs, phi pairs of columns 0, 1, 2), rows 12..15: float4 (signal
-    // pairs), then three v2f rows (pmid): 16 x 1 KB + 3 x 512 B
-    constexpr int kSegBytes = 16 * 1024 + 3 * 512;
-    static_assert(kSegBytes <= 8 * 3 * (2 * kNV + 2) * 64, "a parked segment fits the slot gl_body's format needs");
+    // segment format, per stream, rows of 64 lanes: 3 x kNP float4 rows (column c: plo pairs, then phi pairs), kNV / 2 float4 rows (signal pairs),
+    // then three v2f rows (pmid)
+    constexpr int kPrevRows = 3 * kNP, kSigRows = kNV / 2, kSegBytes = (kPrevRows + kSigRows) * 1024 + 3 * 512;
+    static_assert(kNP % 2 == 0 && kSegBytes <= 8 * 3 * (2 * kNV + 2) * 64, "a parked segment fits the slot gl_body's format needs");
     char* seg = state != nullptr ? reinterpret_cast<char*>(state) + b * (size_t)(8 * 3 * (2 * kNV + 2) * 64) : nullptr;
     auto park_segment = [&]() {
         float4* q = reinterpret_cast<float4*>(seg) + lane;
@@ -148,13 +173,13 @@ __device__ __forceinline__ void glw_body(char* smem, const DspDev& d, const floa
         for (int c = 0; c < 3; ++c) {
 #pragma unroll
             for (int h = 0; h < kNP / 2; ++h) {
-                q[64 * (4 * c + h)] = make_float4(plo[c][2 * h][0], plo[c][2 * h][1], plo[c][2 * h + 1][0], plo[c][2 * h + 1][1]);
-                q[64 * (4 * c + 2 + h)] = make_float4(phi[c][2 * h][0], phi[c][2 * h][1], phi[c][2 * h + 1][0], phi[c][2 * h + 1][1]);
+                q[64 * (kNP * c + h)] = make_float4(plo[c][2 * h][0], plo[c][2 * h][1], plo[c][2 * h + 1][0], plo[c][2 * h + 1][1]);
+                q[64 * (kNP * c + kNP / 2 + h)] = make_float4(phi[c][2 * h][0], phi[c][2 * h][1], phi[c][2 * h + 1][0], phi[c][2 * h + 1][1]);
             }
         }
 #pragma unroll
-        for (int h = 0; h < kNV / 2; ++h) q[64 * (12 + h)] = make_float4(snew[2 * h][0], snew[2 * h][1], snew[2 * h + 1][0], snew[2 * h + 1][1]);
-        v2f* r = reinterpret_cast<v2f*>(seg + 16 * 1024) + lane;
+        for (int h = 0; h < kSigRows; ++h) q[64 * (kPrevRows + h)] = make_float4(snew[2 * h][0], snew[2 * h][1], snew[2 * h + 1][0], snew[2 * h + 1][1]);
+        v2f* r = reinterpret_cast<v2f*>(seg + (kPrevRows + kSigRows) * 1024) + lane;
 #pragma unroll
         for (int c = 0; c < 3; ++c) r[64 * c] = pmid[c];
     };
@@ -174,23 +199,24 @@ __device__ __forceinline__ void glw_body(char* smem, const DspDev& d, const floa
         }
         if (resume == kGlwFromSeg) {
             const float4* q = reinterpret_cast<const float4*>(seg) + lane;
-            float4 pq[12], sq[4];
+            float4 pq[kPrevRows], sq[kSigRows];
 #pragma unroll
-            for (int i = 0; i < 12; ++i) pq[i] = q[64 * i];
+            for (int i = 0; i < kPrevRows; ++i) pq[i] = q[64 * i];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) sq[i] = q[64 * (12 + i)];
-            const v2f* r = reinterpret_cast<const v2f*>(seg + 16 * 1024) + lane;
+            for (int i = 0; i < kSigRows; ++i) sq[i] = q[64 * (kPrevRows + i)];
+            const v2f* r = reinterpret_cast<const v2f*>(seg + (kPrevRows + kSigRows) * 1024) + lane;
 #pragma unroll
             for (int c = 0; c < 3; ++c) pmid[c] = r[64 * c];
 #pragma unroll
             for (int c = 0; c < 3; ++c)
 #pragma unroll
                 for (int h = 0; h < kNP / 2; ++h) {
-                    plo[c][2 * h] = mk2(pq[4 * c + h].x, pq[4 * c + h].y); plo[c][2 * h + 1] = mk2(pq[4 * c + h].z, pq[4 * c + h].w);
-                    phi[c][2 * h] = mk2(pq[4 * c + 2 + h].x, pq[4 * c + 2 + h].y); phi[c][2 * h + 1] = mk2(pq[4 * c + 2 + h].z, pq[4 * c + 2 + h].w);
+                    const float4 lo4 = pq[kNP * c + h], hi4 = pq[kNP * c + kNP / 2 + h];
+                    plo[c][2 * h] = mk2(lo4.x, lo4.y); plo[c][2 * h + 1] = mk2(lo4.z, lo4.w);
+                    phi[c][2 * h] = mk2(hi4.x, hi4.y); phi[c][2 * h + 1] = mk2(hi4.z, hi4.w);
                 }
 #pragma unroll
-            for (int h = 0; h < kNV / 2; ++h) { snew[2 * h] = mk2(sq[h].x, sq[h].y); snew[2 * h + 1] = mk2(sq[h].z, sq[h].w); }
+            for (int h = 0; h < kSigRows; ++h) { snew[2 * h] = mk2(sq[h].x, sq[h].y); snew[2 * h + 1] = mk2(sq[h].z, sq[h].w); }
             // the reflected half columns of the analysis read the signal from the wave's LDS line
 #pragma unroll
             for (int t = 0; t < kNV; ++t) *reinterpret_cast<v2f*>(sl + 2 * (lane + 64 * t)) = snew[t];
@@ -254,51 +280,59 @@ __device__ __forceinline__ void glw_body(char* smem, const DspDev& d, const floa
 
     for (int it = it_begin; it < it_last; ++it) {
         if (it == it_begin + 1) DN_WSTAMP(4);
-        // ---- stft of the rebuilt signal (centre, reflect) -> phase update -> istft, side columns as a pair, then the centre column
-        v2f xlo[3][kNP], xhi[3][kNP], xmid[3];
-        {
-            v2f v[2][kNV];
+        // ---- stft of the rebuilt signal (centre, reflect) -> phase update with momentum -> istft, the side columns first (as a pair of transforms),
+        // then the centre column.  A column's new spectrum goes straight back into its synthesis: only the signal (old and new) and the previous
+        // spectra live across columns.
+        // column 0: n0 < H -> s[H - n0], s[H - n0 - 1] (reflection), else the pair a hop earlier (same lane, register t - kHalf)
+        // column 2: n0 < H -> the pair a hop later (register t + kHalf), else s[3H - 2 - n0], s[3H - 3 - n0] (reflection)
+        auto build0 = [&](v2f (&v)[kNV]) {
 #pragma unroll
             for (int t = 0; t < kNV; ++t) {
                 const int n0 = 2 * (lane + 64 * t);
-                // column 0: n0 < H -> s[H - n0], s[H - n0 - 1] (reflection), else the pair a hop earlier (same lane, register t - 4)
-                // column 2: n0 < H -> the pair a hop later (register t + 4), else s[3H - 2 - n0], s[3H - 3 - n0] (reflection)
                 const v2f s0 = t < kNP ? mk2(sl[kHop - n0], sl[kHop - n0 - 1]) : snew[t - kHalf];
+                v[t] = s0 * cw_t[0 * kNC + lane + 64 * t];
+            }
+        };
+        auto build2 = [&](v2f (&v)[kNV]) {
+#pragma unroll
+            for (int t = 0; t < kNV; ++t) {
+                const int n0 = 2 * (lane + 64 * t);
                 const v2f s2 = t < kNP ? snew[t + kHalf] : mk2(sl[3 * kHop - 2 - n0], sl[3 * kHop - 3 - n0]);
-                v[0][t] = s0 * cw_t[0 * kNC + lane + 64 * t];
-                v[1][t] = s2 * cw_t[2 * kNC + lane + 64 * t];
+                v[t] = s2 * cw_t[2 * kNC + lane + 64 * t];
             }
-            v2f* const tiles[2] = {tile0, tile1};
-            G::Fft::template run_n<false, 2>(v, tw, tiles, lane);
+        };
+        auto advance = [&](const v2f (&v)[kNV], auto col, XP& xlo, XP& xhi, v2f& xmid) {       // split, phase update
+            constexpr int c = decltype(col)::value;
+            v2f rlo[kNP], rhi[kNP], rmid;
+            rfft_split_pairs<kNV>(v, wkh, lane, rlo, rhi, rmid);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int c = 2 * j;
-                v2f rlo[kNP], rhi[kNP], rmid;
-                rfft_split_pairs<kNV>(v[j], wkh, lane, rlo, rhi, rmid);
-#pragma unroll
-                for (int t = 0; t < kNP; ++t) {
-                    update(rlo[t], plo[c][t], xlo[c][t], mlo[c][t]);
-                    update(rhi[t], phi[c][t], xhi[c][t], mhi[c][t]);
-                }
-                update(rmid, pmid[c], xmid[c], mmid[c]);
+            for (int t = 0; t < kNP; ++t) {
+                update(rlo[t], plo[c][t], xlo[t], mlo[c][t]);
+                update(rhi[t], phi[c][t], xhi[t], mhi[c][t]);
             }
+            update(rmid, pmid[c], xmid, mmid[c]);
+        };
+        v2f acc[kNV];
+        {
+            v2f x0lo[kNP], x0hi[kNP], x0mid, x2lo[kNP], x2hi[kNP], x2mid;
+            v2f v[2][kNV];
+            build0(v[0]);
+            build2(v[1]);
+            fft(std::false_type{}, v);
+            advance(v[0], std::integral_constant<int, 0>{}, x0lo, x0hi, x0mid);
+            advance(v[1], std::integral_constant<int, 2>{}, x2lo, x2hi, x2mid);
+            synth_side(x0lo, x0hi, x0mid, x2lo, x2hi, x2mid, acc);
         }
         {
+            v2f x1lo[kNP], x1hi[kNP], x1mid;
             v2f v[1][kNV];
 #pragma unroll
             for (int t = 0; t < kNV; ++t) v[0][t] = snew[t] * cw_t[1 * kNC + lane + 64 * t];
-            v2f* const tiles[1] = {tile0};
-            G::Fft::template run_n<false, 1>(v, tw, tiles, lane);
-            v2f rlo[kNP], rhi[kNP], rmid;
-            rfft_split_pairs<kNV>(v[0], wkh, lane, rlo, rhi, rmid);
-#pragma unroll
-            for (int t = 0; t < kNP; ++t) {
-                update(rlo[t], plo[1][t], xlo[1][t], mlo[1][t]);
-                update(rhi[t], phi[1][t], xhi[1][t], mhi[1][t]);
-            }
-            update(rmid, pmid[1], xmid[1], mmid[1]);
+            fft(std::false_type{}, v);
+            advance(v[0], std::integral_constant<int, 1>{}, x1lo, x1hi, x1mid);
+            synth_centre(x1lo, x1hi, x1mid, acc);
         }
-        synthesize(xlo, xhi, xmid);
+        publish(acc);
     }
     if (park) {          // hand the chain over (uniform)
         DN_WSTAMP(5);

@@ -159,11 +159,10 @@ __global__ __launch_bounds__(kHopPipeThreads, (NFFT == 1536 || GLW) ? 2 : 1) voi
                     const int it0 = (int)meta[5], n_iter = (int)meta[6];
                     const float mom = __builtin_bit_cast(float, meta[7]);
                     float* gl_out = reinterpret_cast<float*>((uint64_t)meta[8] | ((uint64_t)meta[9] << 32));
-                    // iterations [lo, hi) of the frame's chain; the last segment runs to the end and emits.  Drawing a frame's 3 x 513 initial phases
-                    // (27 Philox blocks a lane, ~12 k cycles) costs the first segment about as much as an iteration: it gets one fewer.
+                    // iterations [lo, hi) of the frame's chain; the last segment runs to the end and emits.  (A frame of a deep pipe comes with its
+                    // initial phases in the slot -- injected, or drawn by its front workgroup's spare wave -- so every segment starts alike.)
                     const int span = n_iter > it0 ? n_iter - it0 : 0;
-                    const int draw = (depth > 1 && meta[0] == 0 && it0 == 0) ? 1 : 0;
-                    auto cut = [&](int k) { return k <= 0 ? 0 : k >= depth ? span : max(0, min(span, ((span + draw) * k + depth / 2) / depth - draw)); };
+                    auto cut = [&](int k) { return k <= 0 ? 0 : k >= depth ? span : (span * k + depth / 2) / depth; };
                     const int lo = it0 + cut(seg), hi = it0 + cut(seg + 1);
                     const bool last = seg == depth - 1;
 #ifdef DN_GLW_PRIO
@@ -234,7 +233,9 @@ __global__ __launch_bounds__(kHopPipeThreads, (NFFT == 1536 || GLW) ? 2 : 1) voi
             const int split = min(a.gl_split, a.n_iter);
             // (measured: n_fft 1536, 13 bins a lane: 106 -> 100 us per batch-256 hop; n_fft 1024, 9 bins a lane: 54.7 -> 55.2 us -- the draw's 12 KB
             // a stream through HBM cost more than the multiplies it moved off the chain, so only the long transform uses it)
-            const bool draw = NFFT == 1536 && split > 0 && a.init_in == nullptr;
+            // A deep pipe (a.depth > 1: the chain runs as segments, one wavefront per stream) draws here too, at either transform length: there the
+            // draw is 27 Philox blocks a lane (~12 k cycles) on the first segment's wave, which then has to get an iteration less than the others.
+            const bool draw = a.init_in == nullptr && (NFFT == 1536 ? split > 0 : a.depth > 1);
             if (draw && tid >= kHopThreads) {
                 // The fourth wave has no column to transform and would wait here: it draws the random initial phases the head start
                 // below begins with (the same Philox blocks, so the same bits) into the slot.  One block per bin is ~10 rounds of
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(kHopPipeThreads, (NFFT == 1536 || GLW) ? 2 : 1) voi
             if (tid == 0) {
                 uint32_t* meta = reinterpret_cast<uint32_t*>(slot + sl.meta) + kSlotMeta * b;
                 const uint64_t seed = a.seed + frames;
-                meta[0] = a.init_in != nullptr ? 1u : 0u;
+                meta[0] = (a.init_in != nullptr || (draw && a.depth > 1)) ? 1u : 0u;       // the frame's phases are in the slot
                 meta[1] = (uint32_t)seed;
                 meta[2] = (uint32_t)(seed >> 32);
                 meta[3] = (uint32_t)a.sid0;

@@ -1262,3 +1262,19 @@ def test_host_fed_stream_equals_device_fed_stream(dev, batch, s16, depth, staged
     assert a.dtype == b.dtype and a.shape == b.shape and torch.equal(a, b) and a.abs().max().item() > 0
     for x, y in zip(ra, rb):
         assert torch.equal(x, y)
+
+
+def test_app_parameters_refuse_the_schedules_built_for_n_fft_1024(dev):
+    """At the reference app's own STFT parameters (app3.py:29-33: n_fft 1536) the wavefront-per-stream Griffin-Lim and the deep pipe are not built
+    (the per-lane state of a stream does not fit one wavefront: measured 1.6x slower): the pipe says so instead of doing something else."""
+    from audio_denoising_amd import _lib
+    from audio_denoising_amd.pipeline import Denoiser, HopPipeline
+    p = _params("R1")
+    dn = Denoiser(_model(dev, 4, "dari_tult2"), p.sample_rate, p.n_fft, p.hop, p.n_mels)
+    pipe = HopPipeline(dn, 8)
+    with pytest.raises(RuntimeError, match="1024"):
+        pipe.set_depth(2)
+    with pytest.raises(RuntimeError, match="1024"):
+        pipe.set_gl_schedule(_lib.DN_GL_WAVE_PER_STREAM)
+    pipe.set_gl_schedule(_lib.DN_GL_WAVE_PER_COLUMN)
+    pipe.set_depth(1)

@@ -54,3 +54,76 @@ def test_scatter_gather_world2_gloo(total):
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+class _OneHopPipe:
+    """Stand-in for the software-pipelined hop: launch i reads in_buf NOW (its front half) and completes hop i-1 into the `out` of hop i-1
+    (its Griffin-Lim half) -- the data hazards the double-buffered ingress loop of bench.py has to respect."""
+
+    def __init__(self):
+        self.pending = None
+
+    def submit(self, frames, out):
+        if self.pending is not None:
+            f, o = self.pending
+            o.copy_(f * 2.0)
+        self.pending = (frames.clone(), out)          # (the front half has consumed `frames` when submit returns: launch order)
+
+    def flush(self):
+        if self.pending is not None:
+            f, o = self.pending
+            o.copy_(f * 2.0)
+            self.pending = None
+
+
+def _ingress_worker(rank, world, port, total, steps, q):
+    """bench.ingress_variant's order of operations (there: scatter/gather on a second HIP stream with events between the same steps; here the
+    calls themselves, in that order): scatter(0); per step i: hop(i) -> scatter(i+1) -> gather(i-1); flush; gather(n-1).  Every step carries
+    different audio; in_buf / out_buf are double-buffered, `out=` forms, uneven shards."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lo, hi = shard_range(total, world, rank)
+        B = hi - lo
+        audio = [torch.arange(total * 4, dtype=torch.float32).reshape(total, 4) + 1000.0 * i for i in range(steps)] if rank == 0 else [None] * steps
+        big_out = torch.zeros(total, 4) if rank == 0 else None
+        in_buf = [torch.empty(B, 4) for _ in range(2)]
+        out_buf = [torch.zeros(B, 4) for _ in range(2)]
+        pipe = _OneHopPipe()
+        ok = True
+        scatter_rows(audio[0], total, (4,), torch.float32, "cpu", out=in_buf[0])
+        for i in range(steps):
+            s = i & 1
+            pipe.submit(in_buf[s], out_buf[s])                    # launch i: front of hop i, completes hop i-1 into out_buf[(i-1)&1]
+            if i + 1 < steps:
+                scatter_rows(audio[i + 1], total, (4,), torch.float32, "cpu", out=in_buf[s ^ 1])
+            if i >= 1:
+                gather_rows(out_buf[s ^ 1], total, out=big_out)
+                if rank == 0:
+                    ok = ok and bool(torch.equal(big_out, audio[i - 1] * 2.0))
+        pipe.flush()
+        gather_rows(out_buf[(steps - 1) & 1], total, out=big_out)
+        if rank == 0:
+            ok = ok and bool(torch.equal(big_out, audio[steps - 1] * 2.0))
+            q.put(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [5, 7])
+def test_double_buffered_ingress_order_round_trips_on_uneven_shards(total):
+    """the scatter -> hop -> gather loop of bench.py's `ingress_variant`, with its double buffering and the one-hop delay of the
+    pipelined hop, on two gloo ranks with uneven shards (3 + 2, 4 + 3 rows): every step's audio must come back doubled, step by step."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ingress_worker, args=(r, 2, port, total, 6, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
