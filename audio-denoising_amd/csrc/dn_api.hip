@@ -852,10 +852,10 @@ int dn_pipe_create(const dn_model* m, const dn_dsp* d, int32_t B, uint32_t flags
     if (e != hipSuccess) { dn_pipe_destroy(p); return fail(DN_ERR_HIP, std::string("dn_pipe_create: ") + hipGetErrorString(e)); }
     {
         // Griffin-Lim head start: with at most one stream per CU (MI355X: 256 CUs) a front workgroup has slack at the end of a launch that
-        // the pending hop's chain does not -- measured best at 8 iterations for n_fft 1024 (65.0 -> 56.0 us per batch-256 hop) and 10 for
-        // n_fft 1536 (131 -> 103 us); with more streams than CUs every workgroup is busy throughout and it only adds traffic.
+        // the pending hop's chain does not -- measured best at 8 iterations for n_fft 1024 (65.0 -> 56.0 us per batch-256 hop) and 12 for
+        // n_fft 1536 (131 -> 97 us; round 3, profiles/r03_head_start_sweep.txt); with more streams than CUs every workgroup is busy throughout and it only adds traffic.
         // (The optimum moves up whenever the front half gets shorter: re-run tools/head_start_sweep.sh after changing either half.)
-        const int it = B <= 256 ? (d->cfg.n_fft == 1536 ? 10 : 8) : 0;       // (experiments: dn_pipe_set_head_start, tools/head_start_sweep.sh)
+        const int it = B <= 256 ? (d->cfg.n_fft == 1536 ? 12 : 8) : 0;       // (experiments: dn_pipe_set_head_start, tools/head_start_sweep.sh)
         if (it > 0) { rc = dn_pipe_set_head_start(p, it); if (rc != DN_OK) { dn_pipe_destroy(p); return rc; } }
     }
     *out = p;

@@ -63,7 +63,10 @@ template <int NFFT> constexpr int gl_smem() { return 8 * 3 * Geo<NFFT>::kTile + 
 // One workgroup (192 threads = 3 wavefronts = 3 columns) runs all iterations for stream `b`.  `smem`: gl_smem<NFFT>() bytes.
 // STREAM = true: instead of storing the frame, fold it into the stream's overlap-add line (P12, app3.py:219-224):
 //   hop_out <- ola[:hop] (float, or clipped int16 as app3.py:244-245); ola <- concat(ola[hop:], 0) + frame.
-template <int NFFT, bool FROM_MEL, bool STREAM = false>
+// EXIT_GE: how the loop tests for its last iteration.  Semantically the same (n_last >= it_begin); the compiler lays the loop out differently, and
+// measurably so at n_fft 1536 (256 registers, a few values in scratch): `==` suits the chain that runs to the end (115 -> 103 us per batch-256 hop),
+// `>=` the head start that stops early (its iterations 17.2 k -> 13.5 k ticks).  Each call site of dn_hop.hip uses what measured best.
+template <int NFFT, bool FROM_MEL, bool STREAM = false, bool EXIT_GE = false>
 __device__ __forceinline__ void gl_body(char* smem, const DspDev& d, const float* __restrict__ mag,
                                         const float* __restrict__ diff, const v2f* __restrict__ init, uint64_t seed,
                                         uint64_t sid0, const float* __restrict__ scale, float* __restrict__ wave,
@@ -279,7 +282,7 @@ __device__ __forceinline__ void gl_body(char* smem, const DspDev& d, const float
         DN_STAMP(3);
         __syncthreads();
         DN_STAMP(4);
-        if (it == n_last) {          // (== and not >=: the compiler lays the loop out measurably better, 115 -> 103 us per batch-256 hop at n_fft 1536)
+        if (EXIT_GE ? it >= n_last : it == n_last) {
             // final istft: divide by the window envelope, trim, scale (app3.py:217 `* peak`)
             const float sc = scale != nullptr ? scale[b] : 1.0f;
             if (!STREAM) {

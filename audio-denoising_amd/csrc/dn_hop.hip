@@ -288,7 +288,7 @@ __global__ __launch_bounds__(kHopPipeThreads, (NFFT == 1536 || GLW) ? 2 : 1) voi
                 __syncthreads();                       // the magnitudes are in the slot
                 if (tid >= kHopThreads) return;        // the chain is three waves wide
                 __builtin_amdgcn_s_setprio(DN_HS_PRIO); // below the pending hop's chain (3): that one ends the launch
-                gl_body<NFFT, false, false>(smem, d, slot + sl.lin, nullptr,
+                gl_body<NFFT, false, false, NFFT == 1536>(smem, d, slot + sl.lin, nullptr,
                                             draw ? reinterpret_cast<const v2f*>(slot_init) : reinterpret_cast<const v2f*>(a.init_in), a.seed + frames, a.sid0,
                                             nullptr, nullptr, a.n_iter, a.mom, b, tid, nullptr, nullptr, 0, 0, split,
                                             reinterpret_cast<v2f*>(a.gl_state + (size_t)s * a.state_stride));

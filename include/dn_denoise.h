@@ -258,7 +258,7 @@ int dn_pipe_set_model(dn_pipe* p, const dn_model* m);
 /* Head start: a front workgroup is done with P1-P10 well before the pending hop's Griffin-Lim chain (same launch) is; with
  * `iterations` > 0 it goes on with the first iterations of ITS frame's chain and parks it in HBM, and the next launch resumes there.
  * Same results bit for bit, no added latency; pays when there is about one stream per CU.  dn_pipe_create turns it on by itself up to
- * 256 streams (8 iterations at n_fft 1024, 10 at 1536: the measured optima).  Call between launches (0 = off). */
+ * 256 streams (8 iterations at n_fft 1024, 12 at 1536: the measured optima).  Call between launches (0 = off). */
 int dn_pipe_set_head_start(dn_pipe* p, int32_t iterations);
 /* Depth of the pipe = hops of ONE stream in flight (n_fft 1024; DN_ERR_UNSUPPORTED at 1536, where the per-lane state of a stream does not fit one wavefront).  1 (default): hop n's Griffin-Lim runs beside hop n+1's front half, as
  * described above.  D > 1: a frame's Griffin-Lim chain is cut into D segments that run in the D launches after its submit -- one wavefront
