@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Profiling driver: a few hops at batch 256 (same workload and schedule as bench.py), nothing else.
-    python tools/prof_step.py [steps] [batch] [serial]
+"""Profiling driver: a few hops at batch 256 (same workload and schedule as bench.py: the deep pipe at its default depth), nothing else.
+    python tools/prof_step.py [steps] [batch] [serial | depth]
 Run under rocprofv3 (--kernel-trace --stats, or a --pmc pass) from the repo root."""
 import os
 import sys
@@ -26,6 +26,7 @@ def main():
     else:
         from audio_denoising_amd.pipeline import HopPipeline
         pipe = HopPipeline(dn, batch)
+        pipe.set_depth(int(sys.argv[3]) if len(sys.argv) > 3 else bench.default_depth(batch, bench.N_FFT))
         for i in range(steps):
             pipe.submit(frames, hx, out, seed=1000, stream_id0=0)
         pipe.flush()

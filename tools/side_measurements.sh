@@ -1,14 +1,24 @@
 #!/bin/bash
 # The side measurements quoted in DESIGN.md / profiles/README.md, one JSON line each (tools/side_measurements.sh > profiles/rNN_side_measurements.jsonl)
 cd "$(dirname "$0")/.."
-run() { python bench.py --no-cpu-baseline "$@" 2>/dev/null | tail -1; }
-run                                   # the metric's configuration (batch 256, frame mode, pipelined)
+run() { python bench.py --no-cpu-baseline --no-extras "$@" 2>/dev/null | tail -1; }
+run                                   # the metric's configuration (batch 256, frame mode, deep pipe at its default depth 4)
+run --depth 1                         # one hop in flight: output after the next submit (wavefront per column + head start)
+run --depth 2
+run --depth 3
 run --serial                          # one launch per hop, no added latency
 run --conv bf16                       # BASELINE config 3
 run --stream --graph --batch 1024     # BASELINE config 5 under hipGraph replay
+run --batch 512
+run --batch 768
 run --batch 1024
 run --batch 4096
 run --batch 8192
+run --stream --batch 256 --depth 4
+run --stream --pcie --batch 256 --steps 2000          # host-fed (zero copy from page-locked memory)
+run --stream --pcie --batch 256 --depth 4 --steps 2000
+run --stream --pcie --batch 1024 --steps 1000
+DN_HOST_STAGED=1 run --stream --pcie --batch 1024 --steps 1000
 run --preset R1
 run --preset R1 --batch 1024
 run --preset R2
