@@ -896,7 +896,6 @@ void dn_pipe_destroy(dn_pipe* p) {
 
 int dn_pipe_set_head_start(dn_pipe* p, int32_t iterations) {
     if (!p || iterations < 0) return fail(DN_ERR_INVALID, "dn_pipe_set_head_start: bad argument");
-    if (iterations > 0 && p->depth > 1) return fail(DN_ERR_INVALID, "dn_pipe_set_head_start: a pipe deeper than one hop cuts the chain into segments itself");
     if (iterations > 0 && !p->gl_state) DN_HIP(hipMalloc(reinterpret_cast<void**>(&p->gl_state), p->n_slots * p->state_elems * sizeof(float2)));
     if (iterations > 0 && p->d->cfg.n_fft == 1536) {      // n_fft 1536: the front workgroup's spare wave draws the head start's initial phases into the slot
         int rc = dn_pipe_reserve_parity(p);
@@ -934,7 +933,7 @@ int dn_pipe_set_depth(dn_pipe* p, int32_t depth) {
         int rc = dn_pipe_reserve_parity(p);
         if (rc != DN_OK) return rc;
     }
-    if (depth > 1) p->gl_split = 0;             // the chain is cut into segments instead
+    p->gl_split = 0;                            // (a head start is set per depth: dn_pipe_set_head_start)
     h.slot_next = 0;
     DN_HIP(hipMemcpy(p->ctl, &h, sizeof(h), hipMemcpyHostToDevice));
     return DN_OK;

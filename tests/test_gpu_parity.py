@@ -1093,16 +1093,18 @@ def test_deep_pipe_is_bit_identical_to_depth_one_at_batch_256(dev, depth):
     g = torch.Generator().manual_seed(600 + depth)
     hops = [(0.1 * torch.randn(B, p.n_fft, generator=g)).to(dev) for _ in range(6)]
     inits = [torch.rand(B, p.n_stft, 3, dtype=torch.complex64, generator=g).to(dev) for _ in range(6)]
-    for variant in ("rng", "init+drain"):
+    for variant in ("rng", "init+drain", "rng+head_start"):
         res = []
         for d in (1, depth):
             pipe = HopPipeline(dn, B)
             pipe.set_depth(d)
+            if variant == "rng+head_start" and d > 1:
+                pipe.set_head_start(3)          # the front workgroup runs three iterations first; segment 0 resumes from what it parked
             hx = dn.init_hx(B)
             outs = [torch.empty(B, p.n_fft, device=dev) for _ in hops]
             for i, f in enumerate(hops):
-                pipe.submit(f, hx, outs[i], seed=77, stream_id0=5, init_angles=inits[i] if variant != "rng" else None)
-                if variant != "rng" and i == 2:
+                pipe.submit(f, hx, outs[i], seed=77, stream_id0=5, init_angles=inits[i] if variant == "init+drain" else None)
+                if variant == "init+drain" and i == 2:
                     pipe.flush()
             pipe.flush()
             torch.cuda.synchronize()
