@@ -138,47 +138,57 @@ template <> struct WaveFft<512> {
         dft8<INV>(v);
     }
 
-    // NB independent transforms of one wavefront in lock step (one tile each): every exchange of one transform is in flight while the
-    // butterflies of the others issue -- the wave hides its own LDS round trips (dn_glw_body.hpp: one wavefront per stream).
+    // NB independent transforms of one wavefront, SKEWED by half a pass (one tile each): while transform c waits for an exchange -- its LDS writes
+    // and the strided reads behind them, ~200 ticks -- transform c+1 runs the butterflies of its previous pass, so that only the first exchange of
+    // the group is exposed (dn_glw_body.hpp: one wavefront per stream).  LDS operations of one wave execute in order and the tiles are disjoint, so the
+    // wave_sync()s are compiler barriers only.  Same arithmetic as run().
     template <bool INV, int NB>
     static __device__ __forceinline__ void run_n(v2f (&v)[NB][8], const Tw& tw, v2f* const (&tile)[NB], int lane) {
-#pragma unroll
-        for (int c = 0; c < NB; ++c) dft8<INV>(v[c]);
-        wave_sync();
-#pragma unroll
-        for (int c = 0; c < NB; ++c)
+        const int base = ((lane >> 3) << 6) + (lane & 7);
+        auto put0 = [&](int c) {
+            wave_sync();
 #pragma unroll
             for (int t = 0; t < 8; ++t) tile[c][pad0(8 * lane + t)] = v[c][t];
-        wave_sync();
-#pragma unroll
-        for (int c = 0; c < NB; ++c)
+            wave_sync();
+        };
+        auto get0 = [&](int c) {
 #pragma unroll
             for (int t = 0; t < 8; ++t) v[c][t] = tile[c][pad0(lane + 64 * t)];
+        };
+        auto put1 = [&](int c) {
+            wave_sync();
 #pragma unroll
-        for (int c = 0; c < NB; ++c) {
+            for (int t = 0; t < 8; ++t) tile[c][pad1(base + 8 * t)] = v[c][t];
+            wave_sync();
+        };
+        auto get1 = [&](int c) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) v[c][t] = tile[c][pad1(lane + 64 * t)];
+        };
+        auto pass1 = [&](int c) {
 #pragma unroll
             for (int t = 1; t < 8; ++t) v[c][t] = twmul<INV>(v[c][t], tw.p1[t - 1]);
             dft8<INV>(v[c]);
-        }
-        wave_sync();
-        {
-            const int base = ((lane >> 3) << 6) + (lane & 7);
-#pragma unroll
-            for (int c = 0; c < NB; ++c)
-#pragma unroll
-                for (int t = 0; t < 8; ++t) tile[c][pad1(base + 8 * t)] = v[c][t];
-        }
-        wave_sync();
-#pragma unroll
-        for (int c = 0; c < NB; ++c)
-#pragma unroll
-            for (int t = 0; t < 8; ++t) v[c][t] = tile[c][pad1(lane + 64 * t)];
-#pragma unroll
-        for (int c = 0; c < NB; ++c) {
+        };
+        auto pass2 = [&](int c) {
 #pragma unroll
             for (int t = 1; t < 8; ++t) v[c][t] = twmul<INV>(v[c][t], tw.p2[t - 1]);
             dft8<INV>(v[c]);
+        };
+        // pass 0 of transform 0, its first exchange on the way; then every transform's butterflies sit between another one's write and use
+        dft8<INV>(v[0]);
+        put0(0); get0(0);
+#pragma unroll
+        for (int c = 1; c < NB; ++c) {
+            dft8<INV>(v[c]);                 // (covers the exchange of transform c - 1)
+            put0(c); get0(c);
+            pass1(c - 1);
+            put1(c - 1); get1(c - 1);
         }
+        pass1(NB - 1);
+        put1(NB - 1); get1(NB - 1);
+#pragma unroll
+        for (int c = 0; c < NB; ++c) pass2(c);
     }
 };
 
