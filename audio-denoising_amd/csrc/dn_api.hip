@@ -596,7 +596,10 @@ int dn_dsp_create(const dn_dsp_cfg* cfg, const float* fb_in, const float* pinv_i
                 if (qsteps <= dn::mel_q_steps(N)) qlast |= 1ull << (qsteps - 1);
             }
             if (qsteps > dn::mel_q_steps(N)) { qsteps = 0; qlast = 0; }
-            else o_q = d->arena.add(q.data(), q.size() * 4);
+            else {
+                q.resize((size_t)dn::mel_q_steps(N) * 64 * 2, 0.0f);         // padded to the full schedule with (weight 0, bin 0): the kernel loads every step unconditionally
+                o_q = d->arena.add(q.data(), q.size() * 4);
+            }
         }
         o_ms = d->arena.add(start.data(), M * 4);
         o_ml = d->arena.add(len.data(), M * 4);

@@ -143,21 +143,32 @@ __device__ __forceinline__ void stft_body(char* smem, const DspDev& d, const flo
             // packed schedule (DspDev::mel_q): four lanes share a filter and split its taps, 16 filters a group; a step is one coalesced
             // 8-byte load (weight, bin), one LDS read and one FMA -- 19 steps against 56 taps of ~6 instructions with a lane per filter
             // (80 HTK mels at 16 kHz).  This stage is issue bound: it shares its SIMDs with a Griffin-Lim chain that wins arbitration.
-            constexpr int kMelQSteps = mel_q_steps(NFFT);
+            // The schedule is padded with (weight 0, bin 0) steps to its full length by the plan, so every load below is unconditional; the magnitudes of
+            // sixteen steps are requested from LDS in one go, ahead of their FMAs (fetched step by step between the uniform branches of the group ends,
+            // every step paid its own LDS round trip: 6.8 k of the analysis stage's 19 k ticks).  Same products, same order of accumulation.
+            constexpr int kMelQSteps = mel_q_steps(NFFT), kChunk = 16;
+            static_assert(kMelQSteps % kChunk == 0, "whole chunks");
             float2 q[kMelQSteps];
 #pragma unroll
-            for (int t = 0; t < kMelQSteps; ++t) q[t] = t < qsteps ? d.mel_q[t * 64 + lane] : make_float2(0.0f, 0.0f);
+            for (int t = 0; t < kMelQSteps; ++t) q[t] = d.mel_q[t * 64 + lane];
             float acc = 0.0f;
             int mbase = lane >> 2;
 #pragma unroll
-            for (int t = 0; t < kMelQSteps; ++t) {
-                if (t < qsteps) {                                                  // wave-uniform
-                    acc = fmaf(q[t].x, magbuf[w][__builtin_bit_cast(int, q[t].y)], acc);
-                    if ((d.mel_qlast >> t) & 1ull) {                                 // the group's last step: fold the four lanes of a filter
-                        acc = quad_sum(acc);
-                        if ((lane & 3) == 0) melsum[w][mbase] = acc;
-                        mbase += 16;
-                        acc = 0.0f;
+            for (int c0 = 0; c0 < kMelQSteps; c0 += kChunk) {
+                if (c0 < qsteps) {                                                 // wave-uniform: whole chunks past the schedule do nothing
+                    float mg[kChunk];
+#pragma unroll
+                    for (int i = 0; i < kChunk; ++i) mg[i] = magbuf[w][__builtin_bit_cast(int, q[c0 + i].y)];
+#pragma unroll
+                    for (int i = 0; i < kChunk; ++i) {
+                        const int t = c0 + i;
+                        acc = fmaf(q[t].x, mg[i], acc);                            // (a padded step adds 0 * |X[0]|)
+                        if ((d.mel_qlast >> t) & 1ull) {                             // the group's last step: fold the four lanes of a filter
+                            acc = quad_sum(acc);
+                            if ((lane & 3) == 0) melsum[w][mbase] = acc;
+                            mbase += 16;
+                            acc = 0.0f;
+                        }
                     }
                 }
             }

@@ -562,8 +562,8 @@ def main():
         if on_gpu:
             torch.cuda.synchronize()
 
-    def fence():
-        if pipe is not None:
+    def fence(drain=True):
+        if pipe is not None and drain:
             pipe.flush()
         sync()
         if dist is not None:
@@ -577,14 +577,21 @@ def main():
         for i in range(50):
             step(i)
         sync()
-    for i in range(args.warmup):
+    # Throughput is a steady-state quantity: the pipe stays PRIMED across both boundaries of the timed region (its `depth` hops in flight are
+    # neither drained before t0 nor after the last step), so the K launches between the two barrier + synchronize brackets are K hops of work for
+    # every stream -- the front half of a new hop and one chain segment of each hop in flight -- and nothing else.  The drain is timed right after
+    # and reported beside it (`drain_ms`, `ms_per_step_with_drain`: what a finite job of K hops pays).
+    for i in range(max(args.warmup, 2 * depth)):
         step(i)
-    fence()
+    fence(drain=False)
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
-    fence()
+    fence(drain=False)
     elapsed = time.perf_counter() - t0
+    td = time.perf_counter()
+    fence(drain=True)
+    drain_s = time.perf_counter() - td
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -695,6 +702,10 @@ def main():
                              f"output complete {depth} launch(es) after its submit" + ("" if depth == 1 else
                              "; the Griffin-Lim chain of a frame runs as one segment per launch, one wavefront per stream and segment (bit-identical to depth 1)"),
             "pipeline_depth": depth if pipe is not None else 0,
+            "timed_region": "steady state: K launches between barrier + synchronize brackets, the pipe primed on both sides (each launch = one hop of "
+                            "work for every stream: a new hop's front half + one chain segment of each hop in flight); the drain is timed separately",
+            "drain_ms": round(1e3 * drain_s, 4),
+            "ms_per_step_with_drain": round(1e3 * (elapsed + drain_s) / args.steps, 4),
             "depth1_ms_per_step": round(depth1_ms, 4),
             "serial_ms_per_step": round(serial_ms, 4),
             "whole_path": {"tflops": round(TOTAL_FLOP_PER_FRAME * value / 1e12, 3),
