@@ -833,6 +833,11 @@ static size_t slot_floats(const dn_dsp* d, int32_t B) {
     return (size_t)B * (6 * (size_t)d->cfg.n_mels + 1 + dn::kSlotMeta + 3 * ((size_t)d->cfg.n_fft / 2 + 1));
 }
 
+// the head start a one-hop pipe runs with unless told otherwise (measured optima; none above 256 streams, none on a deep pipe)
+static int default_head_start(const dn_pipe* p) {
+    return p->depth == 1 && p->B <= 256 ? (p->d->cfg.n_fft == 1536 ? 12 : 8) : 0;
+}
+
 int dn_pipe_create(const dn_model* m, const dn_dsp* d, int32_t B, uint32_t flags, dn_pipe** out) {
     if (!out) return fail(DN_ERR_INVALID, "dn_pipe_create: null argument");
     if (B <= 0) return fail(DN_ERR_INVALID, "dn_pipe_create: batch must be positive");
@@ -858,7 +863,7 @@ int dn_pipe_create(const dn_model* m, const dn_dsp* d, int32_t B, uint32_t flags
         // the pending hop's chain does not -- measured best at 8 iterations for n_fft 1024 (65.0 -> 56.0 us per batch-256 hop) and 12 for
         // n_fft 1536 (131 -> 97 us; round 3, profiles/r03_head_start_sweep.txt); with more streams than CUs every workgroup is busy throughout and it only adds traffic.
         // (The optimum moves up whenever the front half gets shorter: re-run tools/head_start_sweep.sh after changing either half.)
-        const int it = B <= 256 ? (d->cfg.n_fft == 1536 ? 12 : 8) : 0;       // (experiments: dn_pipe_set_head_start, tools/head_start_sweep.sh)
+        const int it = default_head_start(p);       // (experiments: dn_pipe_set_head_start, tools/head_start_sweep.sh)
         if (it > 0) { rc = dn_pipe_set_head_start(p, it); if (rc != DN_OK) { dn_pipe_destroy(p); return rc; } }
     }
     *out = p;
@@ -939,7 +944,7 @@ int dn_pipe_set_depth(dn_pipe* p, int32_t depth) {
     p->gl_split = 0;                            // (a head start is set per depth: dn_pipe_set_head_start)
     h.slot_next = 0;
     DN_HIP(hipMemcpy(p->ctl, &h, sizeof(h), hipMemcpyHostToDevice));
-    return DN_OK;
+    return dn_pipe_set_head_start(p, default_head_start(p));      // back to depth 1: the one-hop pipe's default head start again
 }
 
 int dn_pipe_set_gl_schedule(dn_pipe* p, int32_t schedule) {

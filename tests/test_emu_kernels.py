@@ -499,7 +499,7 @@ def _run_pipe(lib, dsp, m, schedule, B, n_hops, g, head_start=0, stream=False, s
     return outs
 
 
-@pytest.mark.parametrize("case", ["frames+head_start", "frames+init", "stream+s16"])
+@pytest.mark.parametrize("case", ["frames+head_start", "stream+s16"])
 def test_griffinlim_one_wavefront_per_stream_is_bit_identical_to_one_per_column(lib, dsp, case):
     """dn_pipe_set_gl_schedule: the wavefront-per-stream Griffin-Lim (four streams a workgroup, the three columns interleaved in one wave,
     overlap-add in registers) must reproduce the three-wave chain bit for bit -- frames, overlap-add lines, emitted hops, hx.  B = 5: a
@@ -536,7 +536,7 @@ def test_deep_pipe_runs_the_chain_in_segments_bit_identically(lib, dsp, depth):
     m = make_model(lib, 5)
     rg = np.random.default_rng(17)
     init = [emu.f32(rg.random((B, 3, P.n_stft, 2))) for _ in range(n_hops)]
-    for kw in (dict(n_iter=7, init=init, flush_after=1),) + ((dict(n_iter=2),) if depth == 2 else ()):
+    for kw in (dict(n_iter=7 if depth == 2 else 3, init=init, flush_after=1),):       # (depth 4 with 3 iterations: an empty segment)
         a = _run_pipe(lib, dsp, m, DN_GL_WAVE_PER_COLUMN, B, n_hops, g, **kw)
         b = _run_pipe(lib, dsp, m, DN_GL_AUTO, B, n_hops, g, depth=depth, **kw)
         for x, y in zip(a, b):
