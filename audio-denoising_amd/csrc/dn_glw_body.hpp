@@ -5,8 +5,8 @@
 // workgroup barrier per iteration that nothing overlaps -- and with several streams per CU the machine stays latency bound: at 1,024 and
 // 8,192 streams the counters see the VALU busy 38 % of the time and 1.4 waves per SIMD (profiles/r03_pmc_saturated.txt).
 // Here a wavefront owns a whole stream:
-//   * the three columns are independent between two overlap-add points, so the wave runs them in lock step (columns 0 and 2 as a pair of
-//     transforms, then column 1): every exchange of one transform is in flight while the butterflies of the other issue;
+//   * the three columns are independent between two overlap-add points, so the wave runs their transforms as one skewed group
+//     (WaveFft::run_n: every exchange of one transform is in flight while the butterflies of the next issue; two LDS tiles serve the three);
 //   * no workgroup barrier at all: the overlap-add is LANE LOCAL -- sample pair (2m, 2m+1) of column 1 meets pair m + 256 of column 0 and
 //     pair m - 256 of column 2, the same lane four registers further -- so the rebuilt signal is summed in registers, written to a
 //     wave-private LDS line once per iteration, and read back only for the two reflected half columns;
@@ -109,55 +109,34 @@ __device__ __forceinline__ void glw_body(char* smem, const DspDev& d, const floa
         const float inv = __builtin_amdgcn_rsqf(fmaf(a[0], a[0], fmaf(a[1], a[1], 1e-32f)));
         x = a * (inv * m);
     };
-    // one or two transforms of this wave in lock step (tile0, tile1)
-    auto fft = [&](auto inv, auto& v) {
+    // the three transforms of this wave, skewed (run_n); two tiles do: transform 2 takes over tile 0 after transform 0's last read of it (in order)
+    auto fft = [&](auto inv, v2f (&v)[3][kNV]) {
         constexpr bool INV = decltype(inv)::value;
-        constexpr int N = sizeof(v) / sizeof(v[0]);
-        v2f* const tiles[2] = {tile0, tile1};
-        if constexpr (N == 2) G::Fft::template run_n<INV, 2>(v, tw, tiles, lane);
-        else {
-            v2f* const one[1] = {tile0};
-            G::Fft::template run_n<INV, 1>(v, tw, one, lane);
-        }
+        v2f* const tiles[3] = {tile0, tile1, tile0};
+        G::Fft::template run_n<INV, 3>(v, tw, tiles, lane);
     };
-    // istft from X = angles * magnitude, into the overlap-add `acc` (the NEXT rebuilt signal): first the side columns (0 and 2, as a pair of
-    // transforms) -- column 0 keeps its second half -> s[n - H], column 2 its first half -> s[n + H], the other halves fall
-    // outside the istft trim -- then the centre column on top: (centre + side) of rounded products, as gl_body
+    // istft from X = angles * magnitude of the three columns (order in the batch: 0, 2, 1) into the NEXT rebuilt signal: column 0 keeps its second half
+    // -> s[n - H], column 2 its first half -> s[n + H] (the other halves fall outside the istft trim), then the centre column on top: (centre + side)
+    // of rounded products, as gl_body.  The new signal becomes THE signal: registers, and the wave's LDS line for the reflected half columns of the
+    // next analysis (this wave's LDS operations execute in order).
     using XP = v2f[kNP];
-    auto synth_side = [&](XP& x0lo, XP& x0hi, v2f x0mid, XP& x2lo, XP& x2hi, v2f x2mid, v2f (&acc)[kNV]) {
-        v2f v[2][kNV];
+    auto synthesize = [&](XP& x0lo, XP& x0hi, v2f x0mid, XP& x2lo, XP& x2hi, v2f x2mid, XP& x1lo, XP& x1hi, v2f x1mid) {
+        v2f v[3][kNV];
         irfft_merge_pairs<kNV>(x0lo, x0hi, x0mid, wkh, lane, v[0]);
         irfft_merge_pairs<kNV>(x2lo, x2hi, x2mid, wkh, lane, v[1]);
+        irfft_merge_pairs<kNV>(x1lo, x1hi, x1mid, wkh, lane, v[2]);
         fft(std::true_type{}, v);
 #pragma unroll
         for (int t = 0; t < kHalf; ++t) {
-            acc[t] = cmul_elem(v[0][t + kHalf], wsyn_t[lane + 64 * (t + kHalf)]);
-            acc[t + kHalf] = cmul_elem(v[1][t], wsyn_t[lane + 64 * t]);
+            snew[t] = cmul_elem(v[0][t + kHalf], wsyn_t[lane + 64 * (t + kHalf)]);
+            snew[t + kHalf] = cmul_elem(v[1][t], wsyn_t[lane + 64 * t]);
         }
-    };
-    auto synth_centre = [&](XP& x1lo, XP& x1hi, v2f x1mid, v2f (&acc)[kNV]) {
-        v2f v[1][kNV];
-        irfft_merge_pairs<kNV>(x1lo, x1hi, x1mid, wkh, lane, v[0]);
-        fft(std::true_type{}, v);
 #pragma unroll
-        for (int t = 0; t < kNV; ++t) acc[t] = cadd(cmul_elem(v[0][t], wsyn_t[lane + 64 * t]), acc[t]);
-    };
-    // the new signal becomes THE signal: registers, and the wave's LDS line for the reflected half columns of the next analysis (this wave's LDS
-    // operations execute in order)
-    auto publish = [&](const v2f (&acc)[kNV]) {
+        for (int t = 0; t < kNV; ++t) snew[t] = cadd(cmul_elem(v[2][t], wsyn_t[lane + 64 * t]), snew[t]);
         wave_sync();
 #pragma unroll
-        for (int t = 0; t < kNV; ++t) {
-            snew[t] = acc[t];
-            *reinterpret_cast<v2f*>(sl + 2 * (lane + 64 * t)) = acc[t];
-        }
+        for (int t = 0; t < kNV; ++t) *reinterpret_cast<v2f*>(sl + 2 * (lane + 64 * t)) = snew[t];
         wave_sync();
-    };
-    auto synthesize = [&](v2f (&xlo)[3][kNP], v2f (&xhi)[3][kNP], v2f (&xmid)[3]) {
-        v2f acc[kNV];
-        synth_side(xlo[0], xhi[0], xmid[0], xlo[2], xhi[2], xmid[2], acc);
-        synth_centre(xlo[1], xhi[1], xmid[1], acc);
-        publish(acc);
     };
 
     const bool park = it_stop >= 0;
@@ -270,7 +249,7 @@ __device__ __forceinline__ void glw_body(char* smem, const DspDev& d, const floa
             }
         }
         DN_WSTAMP(2);
-        if (resume != kGlwFromSeg) synthesize(xlo, xhi, xmid);
+        if (resume != kGlwFromSeg) synthesize(xlo[0], xhi[0], xmid[0], xlo[2], xhi[2], xmid[2], xlo[1], xhi[1], xmid[1]);
         DN_WSTAMP(3);
         if (park && it_begin >= it_last) {        // an empty segment: the chain stays (or, for a new one, is put) where the next segment expects it
             if (resume != kGlwFromSeg) park_segment();
@@ -280,9 +259,8 @@ __device__ __forceinline__ void glw_body(char* smem, const DspDev& d, const floa
 
     for (int it = it_begin; it < it_last; ++it) {
         if (it == it_begin + 1) DN_WSTAMP(4);
-        // ---- stft of the rebuilt signal (centre, reflect) -> phase update with momentum -> istft, the side columns first (as a pair of transforms),
-        // then the centre column.  A column's new spectrum goes straight back into its synthesis: only the signal (old and new) and the previous
-        // spectra live across columns.
+        // ---- stft of the rebuilt signal (centre, reflect) -> phase update with momentum -> istft: the three columns as one skewed group of
+        // transforms in each direction (batch order 0, 2, 1).
         // column 0: n0 < H -> s[H - n0], s[H - n0 - 1] (reflection), else the pair a hop earlier (same lane, register t - kHalf)
         // column 2: n0 < H -> the pair a hop later (register t + kHalf), else s[3H - 2 - n0], s[3H - 3 - n0] (reflection)
         auto build0 = [&](v2f (&v)[kNV]) {
@@ -312,27 +290,19 @@ __device__ __forceinline__ void glw_body(char* smem, const DspDev& d, const floa
             }
             update(rmid, pmid[c], xmid, mmid[c]);
         };
-        v2f acc[kNV];
+        v2f x0lo[kNP], x0hi[kNP], x0mid, x2lo[kNP], x2hi[kNP], x2mid, x1lo[kNP], x1hi[kNP], x1mid;
         {
-            v2f x0lo[kNP], x0hi[kNP], x0mid, x2lo[kNP], x2hi[kNP], x2mid;
-            v2f v[2][kNV];
+            v2f v[3][kNV];
             build0(v[0]);
             build2(v[1]);
+#pragma unroll
+            for (int t = 0; t < kNV; ++t) v[2][t] = snew[t] * cw_t[1 * kNC + lane + 64 * t];
             fft(std::false_type{}, v);
             advance(v[0], std::integral_constant<int, 0>{}, x0lo, x0hi, x0mid);
             advance(v[1], std::integral_constant<int, 2>{}, x2lo, x2hi, x2mid);
-            synth_side(x0lo, x0hi, x0mid, x2lo, x2hi, x2mid, acc);
+            advance(v[2], std::integral_constant<int, 1>{}, x1lo, x1hi, x1mid);
         }
-        {
-            v2f x1lo[kNP], x1hi[kNP], x1mid;
-            v2f v[1][kNV];
-#pragma unroll
-            for (int t = 0; t < kNV; ++t) v[0][t] = snew[t] * cw_t[1 * kNC + lane + 64 * t];
-            fft(std::false_type{}, v);
-            advance(v[0], std::integral_constant<int, 1>{}, x1lo, x1hi, x1mid);
-            synth_centre(x1lo, x1hi, x1mid, acc);
-        }
-        publish(acc);
+        synthesize(x0lo, x0hi, x0mid, x2lo, x2hi, x2mid, x1lo, x1hi, x1mid);
     }
     if (park) {          // hand the chain over (uniform)
         DN_WSTAMP(5);
