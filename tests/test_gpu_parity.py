@@ -1280,3 +1280,34 @@ def test_app_parameters_refuse_the_schedules_built_for_n_fft_1024(dev):
         pipe.set_gl_schedule(_lib.DN_GL_WAVE_PER_STREAM)
     pipe.set_gl_schedule(_lib.DN_GL_WAVE_PER_COLUMN)
     pipe.set_depth(1)
+
+
+def test_captured_push_of_a_deep_pipe_replays(dev):
+    """BASELINE config 5's captured step on a deep pipe: ONE hipGraph-captured dn_pipe_stream_push at depth 4 (which chain segment of which hop a
+    wavefront runs is decided from the device-resident control block, nothing hop-dependent is baked into the launch) replayed twelve times equals
+    twelve eager pushes bit for bit, drain included."""
+    from audio_denoising_amd.pipeline import Denoiser, PipelinedStream
+    p = _params("S")
+    B = 256
+    dn = Denoiser(_model(dev, 5), p.sample_rate, p.n_fft, p.hop, p.n_mels)
+    g = torch.Generator().manual_seed(5)
+    sig = (0.3 * torch.randn(B, 12 * p.hop, generator=g)).clamp(-1, 1).to(dev)
+    outs = {}
+    for mode in ("eager", "graph"):
+        ps = PipelinedStream(dn, B, seed=3)
+        ps.set_depth(4)
+        hop = torch.empty(B, p.hop, device=dev)
+        out = torch.empty(B, p.hop, device=dev)
+        step = ps.graph_step(hop, out) if mode == "graph" else None
+        res = []
+        for i in range(12):
+            hop.copy_(sig[:, i * p.hop:(i + 1) * p.hop])
+            if step is not None:
+                step.replay()
+            else:
+                ps.push_(hop, out)
+            res.append(out.clone())
+        res.append(ps.flush())
+        outs[mode] = torch.cat(res, 1)
+    assert torch.equal(outs["eager"], outs["graph"]) and outs["eager"].abs().max().item() > 1e-3
+    assert not outs["eager"][:, :4 * p.hop].any()          # priming push + four hops of pipeline before the first samples come out
