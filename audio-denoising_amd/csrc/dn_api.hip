@@ -484,6 +484,27 @@ int dn_dsp_create(const dn_dsp_cfg* cfg, const float* fb_in, const float* pinv_i
     for (int k = 0; k <= NC / 2; ++k) { tw1024[2 * k] = (float)cos(2.0 * PI * k / N); tw1024[2 * k + 1] = (float)-sin(2.0 * PI * k / N); }
     size_t o_tw512 = d->arena.add(tw512.data(), tw512.size() * 4), o_tw1024 = d->arena.add(tw1024.data(), tw1024.size() * 4);
     size_t o_win = d->arena.add(d->window.data(), N * 4), o_env = d->arena.add(inv_env.data(), N * 4);
+    size_t o_glw = 0;
+    if (N == 1024) {
+        // the same fp32 products the three-wave Griffin-Lim forms per lane (dn_gl_body.hpp: cw, wsyn), so the two schedules stay bit-identical
+        const int H = N / 2;
+        std::vector<float> t((size_t)4 * NC * 2);
+        for (int m = 0; m < NC; ++m) {
+            const float w0 = d->window[2 * m], w1 = d->window[2 * m + 1];
+            const int n0 = 2 * m, n1 = n0 + 1;
+            for (int c = 0; c < 3; ++c) {
+                int i0, i1;
+                if (c == 1) { i0 = n0; i1 = n1; }
+                else if (c == 0) { i0 = n0 < H ? H - n0 : n0 - H; i1 = n1 < H ? H - n1 : n1 - H; }
+                else { i0 = n0 < H ? n0 + H : 3 * H - 2 - n0; i1 = n1 < H ? n1 + H : 3 * H - 2 - n1; }
+                t[((size_t)c * NC + m) * 2] = w0 * inv_env[i0];
+                t[((size_t)c * NC + m) * 2 + 1] = w1 * inv_env[i1];
+            }
+            t[((size_t)3 * NC + m) * 2] = w0 * (1.0f / (float)NC);
+            t[((size_t)3 * NC + m) * 2 + 1] = w1 * (1.0f / (float)NC);
+        }
+        o_glw = d->arena.add(t.data(), t.size() * 4);
+    }
     size_t o_ms = 0, o_ml = 0, o_mw = 0, o_pinv = 0, o_ginv = 0, o_fb2 = 0;
     bool has_factors = false;
     int maxlen = 0, qsteps = 0;
@@ -615,6 +636,7 @@ int dn_dsp_create(const dn_dsp_cfg* cfg, const float* fb_in, const float* pinv_i
     v.twr = d->arena.ptr<float2>(o_tw1024);
     v.window = d->arena.ptr<float>(o_win);
     v.inv_env = d->arena.ptr<float>(o_env);
+    v.glw_tables = N == 1024 ? d->arena.ptr<float2>(o_glw) : nullptr;
     v.n_mels = M;
     v.mel_maxlen = maxlen;
     v.mel_q = qsteps ? d->arena.ptr<float2>(o_q) : nullptr;

@@ -44,26 +44,20 @@ template <int NFFT> struct GlwLds {
 };
 template <int NFFT> constexpr int glw_smem() { return GlwLds<NFFT>::kTotal; }
 
-// the lane-indexed window tables, once per workgroup (every thread of the workgroup calls this; a workgroup barrier follows)
+// the lane-indexed window tables (cw [3][NC], wsyn [NC]: 16 KB the plan holds ready-made), once per workgroup: every thread of the workgroup copies
+// its share; an LDS-only workgroup barrier follows -- in glw_body for the waves that run a chain (their own loads stay in flight across it), in the
+// kernel for the others
 template <int NFFT, int THREADS>
 __device__ __forceinline__ void glw_fill_tables(char* smem, const DspDev& d, int tid) {
-    using G = Geo<NFFT>;
-    constexpr int kNC = G::kNC, kHop = G::kHop;
-    v2f* cw_t = reinterpret_cast<v2f*>(smem + GlwLds<NFFT>::kCw);
-    v2f* wsyn_t = reinterpret_cast<v2f*>(smem + GlwLds<NFFT>::kWsyn);
-    for (int m = tid; m < kNC; m += THREADS) {
-        const v2f ww = reinterpret_cast<const v2f*>(d.window)[m];
-        wsyn_t[m] = cscale(ww, 1.0f / (float)kNC);
-        const int n0 = 2 * m, n1 = n0 + 1;
+    constexpr int kVec = 4 * Geo<NFFT>::kNC * 8 / 16;              // float4s
+    static_assert(GlwLds<NFFT>::kWsyn == GlwLds<NFFT>::kCw + 8 * 3 * Geo<NFFT>::kNC && kVec % THREADS == 0, "the LDS tables are laid out as the plan's");
+    const float4* src = reinterpret_cast<const float4*>(d.glw_tables);
+    float4* dst = reinterpret_cast<float4*>(smem + GlwLds<NFFT>::kCw);
+    float4 q[kVec / THREADS];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            int i0, i1;
-            if (c == 1) { i0 = n0; i1 = n1; }
-            else if (c == 0) { i0 = n0 < kHop ? kHop - n0 : n0 - kHop; i1 = n1 < kHop ? kHop - n1 : n1 - kHop; }
-            else { i0 = n0 < kHop ? n0 + kHop : 3 * kHop - 2 - n0; i1 = n1 < kHop ? n1 + kHop : 3 * kHop - 2 - n1; }
-            cw_t[c * kNC + m] = mk2(ww[0] * d.inv_env[i0], ww[1] * d.inv_env[i1]);
-        }
-    }
+    for (int i = 0; i < kVec / THREADS; ++i) q[i] = src[tid + THREADS * i];
+#pragma unroll
+    for (int i = 0; i < kVec / THREADS; ++i) dst[tid + THREADS * i] = q[i];
 }
 
 // One wavefront (`lane`, wave `wv` of its workgroup) runs iterations [it_begin, it_stop) of the chain of stream `b` -- or, with it_stop < 0, everything
@@ -79,7 +73,7 @@ template <int NFFT, bool STREAM>
 __device__ __forceinline__ void glw_body(char* smem, const DspDev& d, const float* __restrict__ mag, const v2f* __restrict__ init,
                                          uint64_t seed, uint64_t sid0, const float* __restrict__ scale, float* __restrict__ wave,
                                          int n_iter, float mom, size_t b, int lane, int wv, float* ola, void* hop_out, int out_s16,
-                                         int it_begin, int it_stop, int resume, v2f* __restrict__ state) {
+                                         int it_begin, int it_stop, int resume, v2f* __restrict__ state, int tid) {
     using G = Geo<NFFT>;
     using L = GlwLds<NFFT>;
     constexpr int kNR = G::kNR, kNC = G::kNC, kHop = G::kHop, kBins = G::kBins, kNV = G::kNV, kNP = G::kNP, kTile = G::kTile;
@@ -196,10 +190,6 @@ __device__ __forceinline__ void glw_body(char* smem, const DspDev& d, const floa
                 }
 #pragma unroll
             for (int h = 0; h < kSigRows; ++h) { snew[2 * h] = mk2(sq[h].x, sq[h].y); snew[2 * h + 1] = mk2(sq[h].z, sq[h].w); }
-            // the reflected half columns of the analysis read the signal from the wave's LDS line
-#pragma unroll
-            for (int t = 0; t < kNV; ++t) *reinterpret_cast<v2f*>(sl + 2 * (lane + 64 * t)) = snew[t];
-            wave_sync();
         } else if (resume == kGlwFromX) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -247,6 +237,16 @@ __device__ __forceinline__ void glw_body(char* smem, const DspDev& d, const floa
                 xmid[c] = xmid[c] * mmid[c];
                 pmid[c] = mk2(0.0f, 0.0f);
             }
+        }
+        // every load of this wave's prologue is in flight: now the workgroup's window tables (a straight 16 KB copy) and the LDS-only barrier
+        // that publishes them -- one trip to memory for all of it instead of four in a row
+        glw_fill_tables<NFFT, 64 * kGlwWaves>(smem, d, tid);
+        DN_LDS_BARRIER();
+        if (resume == kGlwFromSeg) {
+            // the reflected half columns of the analysis read the signal from the wave's LDS line
+#pragma unroll
+            for (int t = 0; t < kNV; ++t) *reinterpret_cast<v2f*>(sl + 2 * (lane + 64 * t)) = snew[t];
+            wave_sync();
         }
         DN_WSTAMP(2);
         if (resume != kGlwFromSeg) synthesize(xlo[0], xhi[0], xmid[0], xlo[2], xhi[2], xmid[2], xlo[1], xhi[1], xmid[1]);

@@ -145,9 +145,12 @@ __global__ __launch_bounds__(kHopPipeThreads, (NFFT == 1536 || GLW) ? 2 : 1) voi
             const int sidx = wv / depth, j = wv - sidx * depth;          // stream of the workgroup, frames behind the newest (uniform)
             const size_t b = (size_t)blockIdx.x * a.spb + sidx;
             DN_WSTAMP(0);
-            if (pending) {
+            // the workgroup's window tables: every wave fills its share and meets the others at ONE LDS-only barrier -- a wave that runs a chain
+            // does both inside glw_body, behind the loads of its own prologue; the others here
+            const bool runs = pending && sidx < a.spb && b < (size_t)a.back_B && j < (int)pending;
+            if (pending && !runs) {
                 glw_fill_tables<NFFT, kHopPipeThreads>(smem, d, tid);
-                __syncthreads();
+                DN_LDS_BARRIER();
             }
             DN_WSTAMP(1);
             if (sidx < a.spb && b < (size_t)a.back_B) {          // (a wave without work skips to the ticket: wave 0 always has a stream)
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(kHopPipeThreads, (NFFT == 1536 || GLW) ? 2 : 1) voi
 #endif
                     glw_body<NFFT, STREAM>(smem, d, slot + sl.lin, init, seed, sid0, slot + sl.peak, STREAM ? nullptr : gl_out, n_iter, mom, b, lane, wv,
                                            a.ola, a.hop_out, a.out_s16, lo, last ? -1 : hi, seg > 0 ? kGlwFromSeg : it0 > 0 ? kGlwFromX : kGlwFresh,
-                                           reinterpret_cast<v2f*>(a.gl_state + (size_t)s * a.state_stride));
+                                           reinterpret_cast<v2f*>(a.gl_state + (size_t)s * a.state_stride), tid);
                     DN_WSTAMP(7);
                 }
                 if (STREAM && j == 0 && !completes) {

@@ -12,6 +12,9 @@ struct DspDev {
     const float2* twr;      // [NC/2+1] exp(-2 pi i k / n_fft)
     const float* window;    // [n_fft]  analysis == synthesis window (periodic Hann by default)
     const float* inv_env;   // [n_fft]  1 / (w[i]^2 + w[(i + hop) % n_fft]^2): istft envelope over the kept region
+    // window products of the wavefront-per-stream Griffin-Lim (dn_glw_body.hpp), n_fft 1024 only (else null): [4][NC] complex = for columns 0, 1, 2
+    // the analysis window x 1/envelope of the column's source samples, then the synthesis window / NC -- every workgroup copies them to LDS
+    const float2* glw_tables;
     // banded mel filterbank: filter m covers bins [mel_start[m], mel_start[m]+mel_len[m])
     const int* mel_start;   // [M]
     const int* mel_len;     // [M]
