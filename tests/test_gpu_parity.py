@@ -1113,6 +1113,21 @@ def test_deep_pipe_is_bit_identical_to_depth_one_at_batch_256(dev, depth):
         assert torch.equal(res[0][0], res[1][0])
         for a, b in zip(res[0][1], res[1][1]):
             assert torch.equal(a, b) and torch.isfinite(a).all()
+    # fewer iterations than segments: some (n_iter 1) or all (n_iter 0: Griffin-Lim is the istft of the drawn phases) of the segments are empty
+    for n_iter in (0, 1):
+        dn_few = Denoiser(_model(dev, 5), p.sample_rate, p.n_fft, p.hop, p.n_mels, n_iter=n_iter)
+        few = []
+        for d in (1, depth):
+            pipe = HopPipeline(dn_few, 8)
+            pipe.set_depth(d)
+            hx = dn_few.init_hx(8)
+            outs = [torch.empty(8, p.n_fft, device=dev) for _ in range(depth + 1)]
+            for i in range(depth + 1):
+                pipe.submit(hops[i][:8].contiguous(), hx, outs[i], seed=4)
+            pipe.flush()
+            torch.cuda.synchronize()
+            few.append(torch.stack(outs))
+        assert torch.equal(few[0], few[1]) and torch.isfinite(few[0]).all() and few[0].abs().max().item() > 0
     sig = (0.3 * torch.randn(8, 8 * p.hop, generator=g)).clamp(-1, 1)
     pcm = (sig * 32767.0).to(torch.int16).to(dev)
     sres = []
