@@ -947,22 +947,24 @@ int dn_pipe_set_depth(dn_pipe* p, int32_t depth) {
     DN_HIP(hipMemcpy(&h, p->ctl, sizeof(h), hipMemcpyDeviceToHost));
     if (h.pending != 0) return fail(DN_ERR_INVALID, "dn_pipe_set_depth: hops are in flight (flush first)");
     const int n_slots = depth + 1;
+    // everything the new depth needs is allocated before anything of the old one is given up: a failure leaves the pipe as it was
     float* scratch = nullptr;
     float2* state = nullptr;
-    DN_HIP(hipMalloc(reinterpret_cast<void**>(&scratch), n_slots * p->slot_floats * sizeof(float)));
-    if (depth > 1) {
-        hipError_t e = hipMalloc(reinterpret_cast<void**>(&state), n_slots * p->state_elems * sizeof(float2));
-        if (e != hipSuccess) { (void)hipFree(scratch); return fail(DN_ERR_HIP, std::string("dn_pipe_set_depth: ") + hipGetErrorString(e)); }
+    float2* init = nullptr;         // a deep pipe's front workgroups leave every frame's initial phases in its slot (dn_hop.hip)
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&scratch), n_slots * p->slot_floats * sizeof(float));
+    if (e == hipSuccess && depth > 1) e = hipMalloc(reinterpret_cast<void**>(&state), n_slots * p->state_elems * sizeof(float2));
+    if (e == hipSuccess && depth > 1) e = hipMalloc(reinterpret_cast<void**>(&init), n_slots * p->init_elems * sizeof(float2));
+    if (e != hipSuccess) {
+        if (scratch) (void)hipFree(scratch);
+        if (state) (void)hipFree(state);
+        if (init) (void)hipFree(init);
+        return fail(DN_ERR_HIP, std::string("dn_pipe_set_depth: ") + hipGetErrorString(e));
     }
     (void)hipFree(p->scratch);
     if (p->gl_state) (void)hipFree(p->gl_state);
     if (p->scratch_init) (void)hipFree(p->scratch_init);
-    p->scratch = scratch; p->gl_state = state; p->scratch_init = nullptr;
+    p->scratch = scratch; p->gl_state = state; p->scratch_init = init;
     p->depth = depth; p->n_slots = n_slots;
-    if (depth > 1) {          // a deep pipe's front workgroups leave every frame's initial phases in its slot (dn_hop.hip)
-        int rc = dn_pipe_reserve_parity(p);
-        if (rc != DN_OK) return rc;
-    }
     p->gl_split = 0;                            // (a head start is set per depth: dn_pipe_set_head_start)
     h.slot_next = 0;
     DN_HIP(hipMemcpy(p->ctl, &h, sizeof(h), hipMemcpyHostToDevice));
