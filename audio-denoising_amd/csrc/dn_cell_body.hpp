@@ -477,8 +477,20 @@ __device__ __forceinline__ void cell_body(char* smem, const CellDev& cd, const f
     // two register sets: level L+2 is requested while level L multiplies and level L+1 (requested a phase earlier) is dropped
     // into its buffer -- every request has more than a whole phase to come back from L2
     CellStager<kCellThreads, CT != 0 && kCellThreads == 256> stgA, stgB;
-    stgA.issue(level(0), tid);
-    stgB.issue(level(1), tid);
+    // (experiment knob DN_CELL_NOSTAGE: every level reads its fragments and bias table straight from L2 -- no staging loads, no LDS copies)
+#ifdef DN_CELL_NOSTAGE
+#define DN_STG_ISSUE(s, i) do { } while (0)
+#define DN_STG_COMMIT(s, i) do { } while (0)
+#define DN_LW(i) level(i).w
+#define DN_LB(i) level(i).b
+#else
+#define DN_STG_ISSUE(s, i) s.issue(level(i), tid)
+#define DN_STG_COMMIT(s, i) s.commit(level(i), wbuf[(i) & 1], bbuf[(i) & 1], tid)
+#define DN_LW(i) wbuf[(i) & 1]
+#define DN_LB(i) bbuf[(i) & 1]
+#endif
+    DN_STG_ISSUE(stgA, 0);
+    DN_STG_ISSUE(stgB, 1);
 
     DN_CSTAMP(0);
     if (tid < 8) lds[tid] = 0.0f;
@@ -533,34 +545,34 @@ __device__ __forceinline__ void cell_body(char* smem, const CellDev& cd, const f
             const int i = tid + kCellThreads * r;
             if (i < tt * F) sx[i] = xin[r];
         }
-        stgA.commit(level(0), wbuf[0], bbuf[0], tid);
+        DN_STG_COMMIT(stgA, 0);
         DN_LDS_BARRIER();
         DN_CSTAMP(1);
         // ---- encoder, batched over the chunk (gruunet2.py:136-144); level i multiplies out of buffer i & 1
-        stgA.issue(level(2), tid);
-        if (BF16) mconv_down_bf16<NW, 1, kHidden, 2>(wbuf[0], bbuf[0], sx, sd0, trash, 8 * C, tt, wv, lane);
-        else mconv_down<NW, 1, kHidden, 2>(wbuf[0], bbuf[0], sx, sd0, trash, 8 * C, tt, wv, lane);
-        stgB.commit(level(1), wbuf[1], bbuf[1], tid);
+        DN_STG_ISSUE(stgA, 2);
+        if (BF16) mconv_down_bf16<NW, 1, kHidden, 2>(DN_LW(0), DN_LB(0), sx, sd0, trash, 8 * C, tt, wv, lane);
+        else mconv_down<NW, 1, kHidden, 2>(DN_LW(0), DN_LB(0), sx, sd0, trash, 8 * C, tt, wv, lane);
+        DN_STG_COMMIT(stgB, 1);
         DN_LDS_BARRIER();
         DN_CSTAMP(2);
-        stgB.issue(level(3), tid);
+        DN_STG_ISSUE(stgB, 3);
         DN_CSTAMP(17);
-        if (BF16) mconv_down_bf16<NW, kHidden, kHidden, 2>(wbuf[1], bbuf[1], sd0, sd1, trash, 4 * C, tt, wv, lane);
-        else mconv_down<NW, kHidden, kHidden, 2>(wbuf[1], bbuf[1], sd0, sd1, trash, 4 * C, tt, wv, lane);
+        if (BF16) mconv_down_bf16<NW, kHidden, kHidden, 2>(DN_LW(1), DN_LB(1), sd0, sd1, trash, 4 * C, tt, wv, lane);
+        else mconv_down<NW, kHidden, kHidden, 2>(DN_LW(1), DN_LB(1), sd0, sd1, trash, 4 * C, tt, wv, lane);
         DN_CSTAMP(20);
-        stgA.commit(level(2), wbuf[0], bbuf[0], tid);
+        DN_STG_COMMIT(stgA, 2);
         DN_CSTAMP(21);
         DN_LDS_BARRIER();
         DN_CSTAMP(3);
-        stgA.issue(level(4), tid);
-        if (BF16) mconv_down_bf16<NW, kHidden, kHidden, 1>(wbuf[0], bbuf[0], sd1, sd2, trash, 2 * C, tt, wv, lane);
-        else mconv_down<NW, kHidden, kHidden, 1>(wbuf[0], bbuf[0], sd1, sd2, trash, 2 * C, tt, wv, lane);
-        stgB.commit(level(3), wbuf[1], bbuf[1], tid);
+        DN_STG_ISSUE(stgA, 4);
+        if (BF16) mconv_down_bf16<NW, kHidden, kHidden, 1>(DN_LW(2), DN_LB(2), sd1, sd2, trash, 2 * C, tt, wv, lane);
+        else mconv_down<NW, kHidden, kHidden, 1>(DN_LW(2), DN_LB(2), sd1, sd2, trash, 2 * C, tt, wv, lane);
+        DN_STG_COMMIT(stgB, 3);
         DN_LDS_BARRIER();
         DN_CSTAMP(4);
-        if (BF16) mconv_down_bf16<NW, kHidden, kGates, 1>(wbuf[1], bbuf[1], sd2, sd3, trash, C, tt, wv, lane);
-        else mconv_down<NW, kHidden, kGates, 1>(wbuf[1], bbuf[1], sd2, sd3, trash, C, tt, wv, lane);
-        stgA.commit(level(4), wbuf[0], bbuf[0], tid);
+        if (BF16) mconv_down_bf16<NW, kHidden, kGates, 1>(DN_LW(3), DN_LB(3), sd2, sd3, trash, C, tt, wv, lane);
+        else mconv_down<NW, kHidden, kGates, 1>(DN_LW(3), DN_LB(3), sd2, sd3, trash, C, tt, wv, lane);
+        DN_STG_COMMIT(stgA, 4);
         DN_LDS_BARRIER();
         DN_CSTAMP(5);
         // ---- recurrent part, sequential in t (gruunet2.py:232-240)
@@ -593,7 +605,7 @@ __device__ __forceinline__ void cell_body(char* smem, const CellDev& cd, const f
             }
             // (requested here and not a phase earlier: the first use of the pinned gate fragments above waits for every load in
             // flight, and this one would be a phase old; it is not needed before the second decoder level)
-            if (t == 0) stgB.issue(level(5), tid);
+            if (t == 0) DN_STG_ISSUE(stgB, 5);
             DN_LDS_BARRIER();
             if (tid < kHidden * C) {   // chunk order r, i, n (gruunet2.py:234-240)   (17 C <= 85 < threads)
                 const float* gx = sd3 + (size_t)t * kGates * C;
@@ -608,29 +620,29 @@ __device__ __forceinline__ void cell_body(char* smem, const CellDev& cd, const f
             DN_CSTAMP(6 + t);
         }
         // ---- decoder, batched over the chunk (gruunet2.py:184-199); skips are d2, d1, d0 (the last level has no cat)
-        stgA.issue(level(6), tid);
-        if (BF16) mconv_up_bf16<NW, false, 1>(wbuf[0], bbuf[0], shi, nullptr, su0, trash, C, tt, wv, lane);
-        else mconv_up<NW, false, 1>(wbuf[0], bbuf[0], shi, nullptr, su0, trash, C, tt, wv, lane);
-        stgB.commit(level(5), wbuf[1], bbuf[1], tid);      // requested four phases ago (buffer 1 has been free since the last encoder level)
-        stgB.issue(level(7), tid);
+        DN_STG_ISSUE(stgA, 6);
+        if (BF16) mconv_up_bf16<NW, false, 1>(DN_LW(4), DN_LB(4), shi, nullptr, su0, trash, C, tt, wv, lane);
+        else mconv_up<NW, false, 1>(DN_LW(4), DN_LB(4), shi, nullptr, su0, trash, C, tt, wv, lane);
+        DN_STG_COMMIT(stgB, 5);      // requested four phases ago (buffer 1 has been free since the last encoder level)
+        DN_STG_ISSUE(stgB, 7);
         DN_LDS_BARRIER();
         DN_CSTAMP(9);
-        if (BF16) mconv_up_bf16<NW, true, 1>(wbuf[1], bbuf[1], su0, sd2, su1, trash, 2 * C, tt, wv, lane);
-        else mconv_up<NW, true, 1>(wbuf[1], bbuf[1], su0, sd2, su1, trash, 2 * C, tt, wv, lane);
-        stgA.commit(level(6), wbuf[0], bbuf[0], tid);
+        if (BF16) mconv_up_bf16<NW, true, 1>(DN_LW(5), DN_LB(5), su0, sd2, su1, trash, 2 * C, tt, wv, lane);
+        else mconv_up<NW, true, 1>(DN_LW(5), DN_LB(5), su0, sd2, su1, trash, 2 * C, tt, wv, lane);
+        DN_STG_COMMIT(stgA, 6);
         DN_LDS_BARRIER();
         DN_CSTAMP(10);
         const bool more = t0 + kCellChunk < T;
-        if (more) stgA.issue(level(0), tid);
-        if (BF16) mconv_up_bf16<NW, true, 2>(wbuf[0], bbuf[0], su1, sd1, su2, trash, 4 * C, tt, wv, lane);
-        else mconv_up<NW, true, 2>(wbuf[0], bbuf[0], su1, sd1, su2, trash, 4 * C, tt, wv, lane);
-        stgB.commit(level(7), wbuf[1], bbuf[1], tid);
+        if (more) DN_STG_ISSUE(stgA, 0);
+        if (BF16) mconv_up_bf16<NW, true, 2>(DN_LW(6), DN_LB(6), su1, sd1, su2, trash, 4 * C, tt, wv, lane);
+        else mconv_up<NW, true, 2>(DN_LW(6), DN_LB(6), su1, sd1, su2, trash, 4 * C, tt, wv, lane);
+        DN_STG_COMMIT(stgB, 7);
         DN_LDS_BARRIER();
         DN_CSTAMP(11);
         // last level: one output channel, VALU, fp32 in both precisions; its rows are the model output.  The next chunk's first levels
         // are on their way meanwhile.  (`su0` has been dead since the second decoder level: it carries the skip half's partial sums.)
-        if (more) stgB.issue(level(1), tid);
-        last_up<NW>(wbuf[1], bbuf[1], su2, sd0, out + (b * T + t0) * F, su0, 8 * C, tt, tid, (size_t)F);
+        if (more) DN_STG_ISSUE(stgB, 1);
+        last_up<NW>(DN_LW(7), DN_LB(7), su2, sd0, out + (b * T + t0) * F, su0, 8 * C, tt, tid, (size_t)F);
     }
     __syncthreads();
     DN_CSTAMP(12);
