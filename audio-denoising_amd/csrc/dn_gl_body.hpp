@@ -41,10 +41,20 @@ __device__ __forceinline__ void philox4x32(uint32_t (&c)[4], uint32_t k0, uint32
 
 // real, imag ~ U[0,1) independently (torch.rand(dtype=complex64) semantics), keyed by
 // (seed, global stream id, column, bin) so sharding streams over GPUs does not change results.
-__device__ __forceinline__ v2f rand_angle(uint64_t seed, uint64_t sid, int col, int bin) {
-    uint32_t c[4] = {(uint32_t)bin, (uint32_t)col, (uint32_t)sid, (uint32_t)(sid >> 32)};
+// One Philox block serves the bin PAIR (m, NC - m), m = 0..NC/2: words 0, 1 -> bin m, words 2, 3 -> bin NC - m (counter word 0 = m; the
+// self-paired bin NC/2 takes words 0, 1).  Every user below already owns its bins in such pairs, so a frame costs 3 (NC/2 + 1) blocks, not
+// 3 (NC + 1): the ten rounds of 32x32->64 multiplies are the whole cost of a draw (oracle/philox_ref.py restates the same numbering).
+__device__ __forceinline__ float rand_unit(uint32_t w) { return (float)(w >> 8) * (1.0f / 16777216.0f); }
+__device__ __forceinline__ void rand_angle_pair(uint64_t seed, uint64_t sid, int col, int m, v2f& lo, v2f& hi) {
+    uint32_t c[4] = {(uint32_t)m, (uint32_t)col, (uint32_t)sid, (uint32_t)(sid >> 32)};
     philox4x32(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-    return mk2((float)(c[0] >> 8) * (1.0f / 16777216.0f), (float)(c[1] >> 8) * (1.0f / 16777216.0f));
+    lo = mk2(rand_unit(c[0]), rand_unit(c[1]));
+    hi = mk2(rand_unit(c[2]), rand_unit(c[3]));
+}
+__device__ __forceinline__ v2f rand_angle_mid(uint64_t seed, uint64_t sid, int col, int nc) {
+    v2f lo, hi;
+    rand_angle_pair(seed, sid, col, nc / 2, lo, hi);
+    return lo;
 }
 
 // FROM_MEL = false: `mag` is the linear magnitude [B][3][513] (GriffinLim / istft entry points).
@@ -203,14 +213,14 @@ __device__ __forceinline__ void gl_body(char* smem, const DspDev& d, const float
             mlo[t] = FROM_MEL ? lmag[w * kBinPad + k] : (mag != nullptr ? mag[row + k] : 1.0f);
             mhi[t] = FROM_MEL ? lmag[w * kBinPad + kh] : (mag != nullptr ? mag[row + kh] : 1.0f);
             if (it_begin == 0) {
-                alo[t] = init != nullptr ? init[row + k] : rand_angle(seed, sid0 + b, w, k);
-                ahi[t] = init != nullptr ? init[row + kh] : rand_angle(seed, sid0 + b, w, kh);
+                if (init != nullptr) { alo[t] = init[row + k]; ahi[t] = init[row + kh]; }
+                else rand_angle_pair(seed, sid0 + b, w, k, alo[t], ahi[t]);
             }
             plo[t] = mk2(0.0f, 0.0f);
             phi[t] = mk2(0.0f, 0.0f);
         }
         mmid = FROM_MEL ? lmag[w * kBinPad + kNC / 2] : (mag != nullptr ? mag[row + kNC / 2] : 1.0f);
-        if (it_begin == 0) amid = init != nullptr ? init[row + kNC / 2] : rand_angle(seed, sid0 + b, w, kNC / 2);
+        if (it_begin == 0) amid = init != nullptr ? init[row + kNC / 2] : rand_angle_mid(seed, sid0 + b, w, kNC);
         pmid = mk2(0.0f, 0.0f);
     }
 

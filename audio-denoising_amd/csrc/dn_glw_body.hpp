@@ -219,10 +219,9 @@ __device__ __forceinline__ void glw_body(char* smem, const DspDev& d, const floa
                 for (int c = 0; c < 3; ++c) {
 #pragma unroll
                     for (int t = 0; t < kNP; ++t) {
-                        xlo[c][t] = rand_angle(seed, sid0 + b, c, lane + 64 * t);
-                        xhi[c][t] = rand_angle(seed, sid0 + b, c, kNC - (lane + 64 * t));
+                        rand_angle_pair(seed, sid0 + b, c, lane + 64 * t, xlo[c][t], xhi[c][t]);
                     }
-                    xmid[c] = rand_angle(seed, sid0 + b, c, kNC / 2);
+                    xmid[c] = rand_angle_mid(seed, sid0 + b, c, kNC);
                 }
             }
 #pragma unroll

@@ -40,13 +40,16 @@ void launch_griffinlim(const DspDev& d, const float* mag, const float* init, uin
 
 // The initial phases a Griffin-Lim launch with init_angles == NULL draws for (seed, stream_id0 + stream): [B][3][K] complex, real and imaginary
 // part ~ U[0,1) independently (torchaudio's rand_init=True: torch.rand(complex64), app3.py:149-153), Philox4x32-10 keyed by
-// (seed; bin, column, stream id) -- the same rand_angle() the kernels call, so handing the result back as init_angles reproduces the launch.
+// (seed; bin pair, column, stream id) -- the same rand_angle_pair() the kernels call, so handing the result back as init_angles reproduces the launch.
 __global__ void draw_phases_kernel(float2* __restrict__ out, uint64_t seed, uint64_t sid0, int bins) {
     const size_t b = blockIdx.x / 3;
     const int col = blockIdx.x % 3;
-    for (int k = threadIdx.x; k < bins; k += blockDim.x) {
-        const v2f r = rand_angle(seed, sid0 + b, col, k);
-        out[(b * 3 + col) * bins + k] = make_float2(r[0], r[1]);
+    const int nc = bins - 1;
+    for (int m = threadIdx.x; m <= nc / 2; m += blockDim.x) {          // one block per bin pair (m, nc - m)
+        v2f lo, hi;
+        rand_angle_pair(seed, sid0 + b, col, m, lo, hi);
+        out[(b * 3 + col) * bins + m] = make_float2(lo[0], lo[1]);
+        if (2 * m != nc) out[(b * 3 + col) * bins + nc - m] = make_float2(hi[0], hi[1]);
     }
 }
 void launch_draw_phases(const DspDev& d, float* out, uint64_t seed, uint64_t sid0, int B, hipStream_t st) {

@@ -249,13 +249,16 @@ __global__ __launch_bounds__(kHopPipeThreads, (NFFT == 1536 || GLW) ? 2 : 1) voi
             const bool draw = a.init_in == nullptr && (NFFT == 1536 ? split > 0 : a.depth > 1);
             if (draw && tid >= kHopThreads) {
                 // The fourth wave has no column to transform and would wait here: it draws the random initial phases the head start
-                // below begins with (the same Philox blocks, so the same bits) into the slot.  One block per bin is ~10 rounds of
-                // quarter-rate integer multiplies -- 9 bins a lane cost the head start ~7 k cycles on the launch's critical path.
+                // below begins with (the same Philox blocks, so the same bits) into the slot.  A block is ten rounds of quarter-rate integer
+                // multiplies and serves one bin pair -- drawn by the head start itself they were ~7 k cycles on the launch's critical path.
                 float2* dst = slot_init + b * 3 * kBins;
-                for (int i = tid - kHopThreads; i < 3 * kBins; i += 64) {
-                    const int col = i / kBins, k = i - col * kBins;
-                    const v2f r = rand_angle(a.seed + frames, a.sid0 + b, col, k);
-                    dst[i] = make_float2(r[0], r[1]);
+                constexpr int kPairs = (kBins - 1) / 2 + 1;                 // one block per bin pair (m, NC - m), m = 0..NC/2
+                for (int i = tid - kHopThreads; i < 3 * kPairs; i += 64) {
+                    const int col = i / kPairs, m = i - col * kPairs;
+                    v2f lo, hi;
+                    rand_angle_pair(a.seed + frames, a.sid0 + b, col, m, lo, hi);
+                    dst[col * kBins + m] = make_float2(lo[0], lo[1]);
+                    if (2 * m != kBins - 1) dst[col * kBins + kBins - 1 - m] = make_float2(hi[0], hi[1]);
                 }
             }
             __syncthreads();

@@ -115,10 +115,12 @@ def staged_kernel_times(dn, frames, hx, steps):
 
 
 def default_depth(batch, n_fft):
-    """Hops of one stream in flight (dn_pipe_set_depth) for throughput: enough that every CU of an MI355X (256) holds about four chains."""
+    """Hops of one stream in flight (dn_pipe_set_depth) for throughput: enough that every CU of an MI355X (256) holds about four chains
+    (measured, tools/pipe_time.py: 384 streams 4; 512 / 768 / 896 streams 6.1 / 6.3 / 6.4 M frames/s at depth 2 against 5.0 / 5.1 / 5.9 M at
+    depth 1; from 1,024 streams on depth 1 is the fastest)."""
     if n_fft != 1024:
         return 1
-    return 4 if batch <= 384 else 2 if batch < 768 else 1
+    return 4 if batch <= 384 else 2 if batch < 1024 else 1
 
 
 def prewarm(step, seconds=0.3):

@@ -182,8 +182,9 @@ int dn_griffinlim(const dn_dsp* d, const float* mag, const float* init_angles, u
 
 /* The initial phases dn_griffinlim / dn_synthesis / the fused hops draw when init_angles is NULL, for streams stream_id0 .. stream_id0 + B - 1:
  * angles_out [dev][B][3][K] complex, real and imaginary part ~ U[0,1) independently (torchaudio's GriffinLim(rand_init=True) =
- * torch.rand(complex64), app3.py:149-153).  Generator: Philox4x32-10 (Salmon et al., SC'11), counter = (bin, column, stream id lo, hi),
- * key = (seed lo, hi), words 0 and 1 of the block, top 24 bits each -- so the draw does not depend on how streams are batched or sharded.
+ * torch.rand(complex64), app3.py:149-153).  Generator: Philox4x32-10 (Salmon et al., SC'11), one block per bin PAIR (m, K-1-m), m = 0..(K-1)/2:
+ * counter = (m, column, stream id lo, hi), key = (seed lo, hi); words 0, 1 of the block are bin m, words 2, 3 bin K-1-m (the self-paired
+ * middle bin takes words 0, 1), top 24 bits each -- so the draw does not depend on how streams are batched or sharded.
  * Feeding the result back as init_angles reproduces the NULL launch bit for bit (and lets a CPU reference run with the same phases). */
 int dn_griffinlim_draw_phases(const dn_dsp* d, uint64_t seed, uint64_t stream_id0, float* angles_out, int32_t B, void* stream);
 

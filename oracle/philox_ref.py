@@ -29,15 +29,18 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
 
 
 def draw_phases(seed, stream_id0, batch, n_stft):
-    """complex64 (batch, n_stft, 3): what dn_griffinlim_draw_phases must return."""
+    """complex64 (batch, n_stft, 3): what dn_griffinlim_draw_phases must return.  One block per bin PAIR (m, NC - m), NC = n_stft - 1,
+    m = 0..NC/2, counter (m, column, stream id lo, hi): words 0, 1 -> bin m, words 2, 3 -> bin NC - m (csrc/dn_gl_body.hpp rand_angle_pair)."""
     out = np.empty((batch, n_stft, 3), np.complex64)
-    bins = np.arange(n_stft, dtype=np.uint64)
+    nc = n_stft - 1
+    m = np.arange(nc // 2 + 1, dtype=np.uint64)
+    n = len(m)
+    unit = lambda w: (w >> np.uint64(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)  # noqa: E731
     for b in range(batch):
         sid = stream_id0 + b
         for col in range(3):
-            w = philox4x32_10(bins, np.full(n_stft, col, np.uint64), np.full(n_stft, sid & 0xFFFFFFFF, np.uint64),
-                              np.full(n_stft, (sid >> 32) & 0xFFFFFFFF, np.uint64), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
-            re = (w[0] >> np.uint64(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
-            im = (w[1] >> np.uint64(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
-            out[b, :, col] = re + 1j * im
+            w = philox4x32_10(m, np.full(n, col, np.uint64), np.full(n, sid & 0xFFFFFFFF, np.uint64),
+                              np.full(n, (sid >> 32) & 0xFFFFFFFF, np.uint64), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+            out[b, nc - m.astype(np.int64), col] = unit(w[2]) + 1j * unit(w[3])
+            out[b, m.astype(np.int64), col] = unit(w[0]) + 1j * unit(w[1])          # (bin NC/2 pairs with itself: words 0, 1)
     return out
