@@ -34,6 +34,7 @@ DN_PRE_WINDOW = 2
 DN_CONV_BF16 = 1
 DN_GL_AUTO, DN_GL_WAVE_PER_COLUMN, DN_GL_WAVE_PER_STREAM = 0, 1, 2
 DN_HOST_STAGED = 1
+DN_HOST_DEFER = 2
 ABI_VERSION = 3
 
 

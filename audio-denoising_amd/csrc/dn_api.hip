@@ -148,6 +148,13 @@ struct HostIo {
     unsigned long long* done_dev = nullptr;
     unsigned long long zero_copy_pushes = 0;       // pushes whose completion is published there (the others: ev_d2h)
     bool last_zero_copy[kRing] = {};
+    // DN_HOST_DEFER: the emitted hop of the newest push waits in z_out[ticket & 1] until the next launch (or dn_pipe_stream_host_wait) moves it out
+    void* z_out[2] = {nullptr, nullptr};
+    bool defer_pending = false;
+    unsigned long long defer_ticket = 0;
+    void* defer_dst = nullptr;                     // device view of that push's hop_out_host
+    size_t defer_bytes = 0;
+    hipStream_t defer_stream = nullptr;
 };
 
 struct dn_pipe {
@@ -170,6 +177,9 @@ struct dn_pipe {
     // streaming mode: per-stream state owned by the pipe
     unsigned long long* host_done = nullptr;  // set around a zero-copy host push (dn_pipe_stream_push_host)
     unsigned long long host_done_value = 0;
+    const void* host_copy_src = nullptr;      // (likewise: the deferred output the launch carries to the host)
+    void* host_copy_dst = nullptr;
+    size_t host_copy_bytes = 0;
     float* ring = nullptr;                    // [B][n_fft] last n_fft input samples
     float* ola = nullptr;                     // [B][n_fft] output overlap-add line
     float* hx = nullptr;                      // [B][17][C]
@@ -906,6 +916,7 @@ void dn_pipe_destroy(dn_pipe* p) {
         for (int i = 0; i < 2; ++i) {
             if (h->d_in[i]) (void)hipFree(h->d_in[i]);
             if (h->d_out[i]) (void)hipFree(h->d_out[i]);
+            if (h->z_out[i]) (void)hipFree(h->z_out[i]);
         }
         if (h->h2d) (void)hipStreamDestroy(h->h2d);
         if (h->d2h) (void)hipStreamDestroy(h->d2h);
@@ -1090,6 +1101,8 @@ int dn_pipe_stream_push(dn_pipe* p, const void* hop_in, int32_t in_is_s16, void*
     if (rc != DN_OK) return rc;
     a.front_B = p->B; a.hx = p->hx;
     a.host_done = p->host_done; a.host_done_value = p->host_done_value;
+    a.host_copy_src = static_cast<const uint4*>(p->host_copy_src); a.host_copy_dst = static_cast<uint4*>(p->host_copy_dst);
+    a.host_copy_n16 = (unsigned int)(p->host_copy_bytes / 16);
     a.hop_in = hop_in; a.ring = p->ring; a.in_s16 = in_is_s16;
     a.ola = p->ola; a.hop_out = hop_out; a.out_s16 = out_is_s16;
     dn::launch_hop(p->d->view, p->bs->view, a, p->bf16, as_stream(stream));
@@ -1131,32 +1144,61 @@ static void* device_view(const void* host) {
     return dp;
 }
 
+// the deferred output of the newest push, when no further launch will carry it: a copy launch and a one-thread launch that publishes it
+static int host_defer_drain(HostIo* h, hipStream_t st) {
+    if (!h->defer_pending) return DN_OK;
+    dn::launch_host_copy(static_cast<const uint4*>(h->z_out[h->defer_ticket & 1]), static_cast<uint4*>(h->defer_dst), (unsigned int)(h->defer_bytes / 16),
+                         h->done_dev, h->defer_ticket + 1, st);
+    h->defer_pending = false;
+    return check_launch("host_copy_kernel");
+}
+
 int dn_pipe_stream_push_host(dn_pipe* p, const void* hop_in_host, int32_t in_is_s16, void* hop_out_host, int32_t out_is_s16, uint64_t seed,
                              uint64_t stream_id0, int32_t n_iter, float momentum, uint32_t flags, void* stream, uint64_t* ticket) {
     if (!p || !p->ring) return fail(DN_ERR_INVALID, "dn_pipe_stream_push_host: not a streaming pipe");
     if (!hop_in_host || !hop_out_host) return fail(DN_ERR_INVALID, "dn_pipe_stream_push_host: null argument");
-    if (flags & ~(uint32_t)DN_HOST_STAGED) return fail(DN_ERR_INVALID, "dn_pipe_stream_push_host: unknown flag bits");
+    if (flags & ~(uint32_t)(DN_HOST_STAGED | DN_HOST_DEFER)) return fail(DN_ERR_INVALID, "dn_pipe_stream_push_host: unknown flag bits");
     int rc = host_io_init(p);
     if (rc != DN_OK) return rc;
     HostIo* h = p->hio;
     hipStream_t cs = as_stream(stream);
+    const size_t out_bytes = (size_t)p->B * p->d->cfg.hop * (out_is_s16 ? sizeof(short) : sizeof(float));
     if (!(flags & DN_HOST_STAGED)) {
         // zero copy: page-locked host memory is in the device's address space.  The front workgroups read their stream's hop (1 KB) straight from it
         // and the Griffin-Lim workgroups store the emitted hop straight into it -- no copy engine, no second queue, no cross-queue event.
         void* din = device_view(hop_in_host);
         void* dout = device_view(hop_out_host);
         if (din && dout) {
-            p->host_done = h->done_dev;                         // picked up by the launch below: its last workgroup stores pushes + 1 there
-            p->host_done_value = h->pushes + 1;
-            rc = dn_pipe_stream_push(p, din, in_is_s16, dout, out_is_s16, nullptr, seed, stream_id0, n_iter, momentum, stream);
+            const bool defer = (flags & DN_HOST_DEFER) != 0 && out_bytes % 16 == 0;
+            void* kout = dout;
+            if (defer) {
+                // the launch leaves its emitted hop in a device staging buffer; the NEXT launch (or dn_pipe_stream_host_wait) moves it to dout
+                void*& z = h->z_out[h->pushes & 1];
+                if (!z) DN_HIP(hipMalloc(&z, (size_t)p->B * p->d->cfg.hop * sizeof(float)));
+                kout = z;
+            }
+            if (h->defer_pending) {                              // this launch carries the previous push's hop out, spread over its threads
+                p->host_copy_src = h->z_out[h->defer_ticket & 1];
+                p->host_copy_dst = h->defer_dst;
+                p->host_copy_bytes = h->defer_bytes;
+            }
+            // picked up by the launch below: its last workgroup publishes how many pushes have their samples in host memory once it returns
+            p->host_done = defer && !h->defer_pending ? nullptr : h->done_dev;
+            p->host_done_value = defer ? h->pushes : h->pushes + 1;
+            rc = dn_pipe_stream_push(p, din, in_is_s16, kout, out_is_s16, nullptr, seed, stream_id0, n_iter, momentum, stream);
             p->host_done = nullptr;
+            p->host_copy_src = nullptr; p->host_copy_dst = nullptr; p->host_copy_bytes = 0;
             if (rc != DN_OK) return rc;
+            h->defer_pending = defer;
+            if (defer) { h->defer_ticket = h->pushes; h->defer_dst = dout; h->defer_bytes = out_bytes; h->defer_stream = cs; }
             h->last_zero_copy[h->pushes % HostIo::kRing] = true;
             if (ticket) *ticket = h->pushes;
             ++h->pushes;
             return DN_OK;
         }
     }
+    rc = host_defer_drain(h, cs);                                // (a staged push behind a deferred one: its hop leaves first)
+    if (rc != DN_OK) return rc;
     const int s = (int)(h->pushes & 1);                                  // device staging buffer
     const int e = (int)(h->pushes % HostIo::kRing), e2 = (int)((h->pushes + HostIo::kRing - 2) % HostIo::kRing);      // this push's events; those of two pushes ago
     const size_t n = (size_t)p->B * p->d->cfg.hop;
@@ -1185,6 +1227,10 @@ int dn_pipe_stream_host_wait(dn_pipe* p, uint64_t ticket) {
     if (!p || !p->hio) return fail(DN_ERR_INVALID, "dn_pipe_stream_host_wait: no host push was made on this pipe");
     HostIo* h = p->hio;
     if (ticket >= h->pushes) return fail(DN_ERR_INVALID, "dn_pipe_stream_host_wait: no such push");
+    if (h->defer_pending && ticket >= h->defer_ticket) {         // its samples are still in the staging buffer and no launch is queued to move them
+        int rc = host_defer_drain(h, h->defer_stream);
+        if (rc != DN_OK) return rc;
+    }
     // the last kRing pushes still own their events; the download queue is in order, so for an older push the oldest event still alive will do
     const uint64_t oldest = h->pushes > (uint64_t)HostIo::kRing ? h->pushes - HostIo::kRing : 0;
     const uint64_t e = ticket > oldest ? ticket : oldest;

@@ -125,6 +125,12 @@ __global__ __launch_bounds__(kHopPipeThreads, (NFFT == 1536 || GLW) ? 2 : 1) voi
     const unsigned int pending = a.ctl->pending, slot_next = a.ctl->slot_next;
     const SlotLayout sl(a.B, d.n_mels, kBins);
     const bool priming = STREAM && pushes < (unsigned long long)a.prime;
+    if (STREAM && a.host_copy_src != nullptr) {
+        // the previous push's emitted hop: device staging buffer -> its page-locked host buffer (every thread of the grid, before the roles part:
+        // the stores are posted and drain while the hop computes; the last workgroup's system-scope fence below covers them)
+        for (unsigned int u = blockIdx.x * kHopPipeThreads + tid; u < a.host_copy_n16; u += gridDim.x * kHopPipeThreads)
+            a.host_copy_dst[u] = a.host_copy_src[u];
+    }
 #ifdef DN_PROBE
     if (tid == 0 && blockIdx.x < 2048) {
         unsigned int hw, xcc;
@@ -349,6 +355,20 @@ static void launch_hop_n(const DspDev& d, const CellDev& c, const HopArgs& a, bo
 }
 
 // a.glw: the caller laid the grid out for a wavefront per stream and chain segment (n_fft 1024 only) instead of a wavefront per column
+// The deferred host output of the LAST push (no further launch will carry it): copy, then publish (dn_pipe_stream_host_wait).
+__global__ void host_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, unsigned int n16) {
+    for (unsigned int u = blockIdx.x * blockDim.x + threadIdx.x; u < n16; u += gridDim.x * blockDim.x) dst[u] = src[u];
+}
+__global__ void host_publish_kernel(unsigned long long* done, unsigned long long value) {
+    __threadfence_system();
+    __hip_atomic_store(done, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+void launch_host_copy(const uint4* src, uint4* dst, unsigned int n16, unsigned long long* done, unsigned long long value, hipStream_t st) {
+    const unsigned int blocks = (n16 + 255) / 256;
+    hipLaunchKernelGGL(host_copy_kernel, dim3(blocks < 1024 ? (blocks ? blocks : 1) : 1024), dim3(256), 0, st, src, dst, n16);
+    hipLaunchKernelGGL(host_publish_kernel, dim3(1), dim3(1), 0, st, done, value);      // (stream order: the copy has completed)
+}
+
 void launch_hop(const DspDev& d, const CellDev& c, const HopArgs& a, bool bf16, hipStream_t st) {
     const bool stream = a.ola != nullptr;
     if (d.n_fft == 1536) {

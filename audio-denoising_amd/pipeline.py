@@ -352,19 +352,22 @@ class HostFedStream(PipelinedStream):
     """``PipelinedStream`` fed from HOST buffers, as the reference feeds its hop (int16 frames on the host, ``.to(device)`` / ``.cpu()`` around
     the model: app3.py:168-172,189,215,244-250) -- with the transfers overlapped: ``dn_pipe_stream_push_host`` uploads hop i+1 and downloads
     the result of hop i-1 on two copy queues while hop i computes (device staging double-buffered; page-locked rings of four buffers here).
-    ``push(hop)`` takes a CPU tensor ``(B, hop_length)`` (int16 or float32) and returns the samples emitted ``LAG`` = 2 pushes earlier (zeros
-    until then): the host stays two pushes ahead of the GPU, so it never waits for a hop that is still computing and the GPU never waits
-    for the host.  ``drain()`` returns what is still on its way.  Same samples as the device-fed stream, bit for bit."""
+    ``push(hop)`` takes a CPU tensor ``(B, hop_length)`` (int16 or float32) and returns the samples emitted ``LAG`` pushes earlier (zeros
+    until then): the host stays two launches ahead of the GPU, so it never waits for a hop that is still computing and the GPU never waits
+    for the host.  ``drain()`` returns what is still on its way.  Same samples as the device-fed stream, bit for bit.
+    ``defer`` (default, zero copy only): a hop's samples leave the device during the NEXT launch (``DN_HOST_DEFER``), spread over it instead
+    of ending their own launch as one PCIe burst -- ``LAG`` is 3 then, 2 otherwise."""
 
-    LAG = 2
     RING = 4
 
     def __init__(self, denoiser: "Denoiser", batch: int, stream_id0: int = 0, seed: int = 0, s16: bool = True, depth: int = 1,
-                 staged: bool = False):
+                 staged: bool = False, defer: bool = True):
         super().__init__(denoiser, batch, stream_id0, seed)
         if depth != 1:
             self.set_depth(depth)
-        self._hflags = _lib.DN_HOST_STAGED if staged else 0    # default: zero copy (the launch reads / writes the page-locked buffers itself)
+        # default: zero copy (the launch reads the page-locked input itself; its output follows one launch later, or directly with defer=False)
+        self._hflags = _lib.DN_HOST_STAGED if staged else (_lib.DN_HOST_DEFER if defer else 0)
+        self.LAG = 3 if (defer and not staged) else 2
         dt = torch.int16 if s16 else torch.float32
         self._pin_in = [torch.zeros(batch, denoiser.hop, dtype=dt).pin_memory() for _ in range(self.RING)]
         self._pin_out = [torch.zeros(batch, denoiser.hop, dtype=dt).pin_memory() for _ in range(self.RING)]

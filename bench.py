@@ -297,9 +297,12 @@ def side_measurement(args, dn, B, dev):
         # on three queues, double-buffered -- beside the same stream fed from device memory
         from audio_denoising_amd.pipeline import HostFedStream
         staged = os.environ.get("DN_HOST_STAGED") == "1"
-        hs = HostFedStream(dn, B, s16=True, depth=args.depth if args.depth > 0 else 1, staged=staged)
+        direct = os.environ.get("DN_HOST_DIRECT") == "1"
+        hs = HostFedStream(dn, B, s16=True, depth=args.depth if args.depth > 0 else 1, staged=staged, defer=not direct)
         hop_h = (0.1 * torch.randn(B, dn.hop, generator=g) * 32767.0).to(torch.int16)
-        mode = f"stream+pcie (int16 hops in pinned host memory, {'staged copies on two queues' if staged else 'zero copy'}), depth {hs.depth}"
+        how = "staged copies on two queues" if staged else "zero copy, output stored straight to host memory" if direct else \
+            "zero copy, output carried out by the next launch"
+        mode = f"stream+pcie (int16 hops in pinned host memory, {how}), depth {hs.depth}"
 
         def step(i):
             hs.push(hop_h, copy=False)
@@ -355,14 +358,20 @@ def side_measurement(args, dn, B, dev):
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
+    # steady state, as the headline: K launches between synchronize brackets with the pipe primed on both sides (every launch carries one hop of
+    # work for every stream); the drain (flush of the hops in flight, first-use allocations and the pageable copy of its result included) is
+    # timed separately -- at K = 2,000 it used to add 6 us per step to the host-fed line
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
-    fin()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    fin()
+    torch.cuda.synchronize()
+    drain = time.perf_counter() - t0 - el
     print(json.dumps({"metric": "frames/s (side measurement, not the headline)", "preset": args.preset, "mode": mode, "conv": args.conv,
                       "value": round(B * args.steps / el, 1), "unit": "frames/s", "streams": B, "ms_per_step": round(1e3 * el / args.steps, 4),
+                      "drain_ms": round(1e3 * drain, 3), "timed_region": "steady state (pipe primed on both sides); drain timed separately",
                       "n_fft": dn.n_fft, "hop": dn.hop, "n_mels": dn.n_mels, "sample_rate": dn.sample_rate,
                       "realtime_streams_per_gpu": int(B * args.steps / el / (dn.sample_rate / dn.hop))}), flush=True)
 

@@ -1252,11 +1252,14 @@ def test_device_rng_known_answers_and_statistics(dev):
     assert torch.equal(a, b) and torch.equal(ha, hb)
 
 
-@pytest.mark.parametrize("batch,s16,depth,staged", [(256, True, 1, False), (1024, True, 1, False), (7, False, 1, False), (256, True, 4, False),
-                                                    (256, True, 1, True), (1024, True, 1, True), (5, False, 4, True)])
-def test_host_fed_stream_equals_device_fed_stream(dev, batch, s16, depth, staged):
-    """dn_pipe_stream_push_host (app3.py:168-172,189,215,244-250: hops cross the host/device boundary): zero copy (the launch reads and writes
-    page-locked host memory itself) or staged (uploads and downloads on two copy queues beside the hop, device staging double-buffered).
+@pytest.mark.parametrize("batch,s16,depth,staged,defer", [(256, True, 1, False, True), (1024, True, 1, False, True), (7, False, 1, False, True),
+                                                          (256, True, 4, False, True), (5, True, 4, False, True),
+                                                          (256, True, 1, False, False), (7, False, 1, False, False), (256, True, 4, False, False),
+                                                          (256, True, 1, True, False), (1024, True, 1, True, False), (5, False, 4, True, False)])
+def test_host_fed_stream_equals_device_fed_stream(dev, batch, s16, depth, staged, defer):
+    """dn_pipe_stream_push_host (app3.py:168-172,189,215,244-250: hops cross the host/device boundary): zero copy (the launch reads page-locked
+    host memory itself; its emitted hop goes straight to host memory, or -- deferred -- waits in a device buffer and is carried out by the next
+    launch) or staged (uploads and downloads on two copy queues beside the hop, device staging double-buffered).
     Whatever overlaps, the samples must be those of the device-fed stream bit for bit (int16 transport at 256 and 1,024 streams, float32
     at an odd batch, a deep pipe), and so must the stream state left behind."""
     from audio_denoising_amd.pipeline import Denoiser, HostFedStream, PipelinedStream
@@ -1271,7 +1274,8 @@ def test_host_fed_stream_equals_device_fed_stream(dev, batch, s16, depth, staged
     ref.set_depth(depth)
     a = torch.cat([ref.push(h.to(dev)) for h in hops] + [ref.flush(s16=s16)], 1).cpu()
     ra = [t.cpu() for t in ref.state()[:3]]
-    hs = HostFedStream(dn, batch, seed=11, stream_id0=2, s16=s16, depth=depth, staged=staged)
+    hs = HostFedStream(dn, batch, seed=11, stream_id0=2, s16=s16, depth=depth, staged=staged, defer=defer)
+    assert hs.LAG == (3 if defer else 2)
     outs = [hs.push(h) for h in hops]
     assert not torch.cat(outs[:hs.LAG], 1).any()    # a push hands out what was emitted LAG pushes earlier
     b = torch.cat(outs[hs.LAG:] + [hs.drain()], 1)
@@ -1279,6 +1283,45 @@ def test_host_fed_stream_equals_device_fed_stream(dev, batch, s16, depth, staged
     assert a.dtype == b.dtype and a.shape == b.shape and torch.equal(a, b) and a.abs().max().item() > 0
     for x, y in zip(ra, rb):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("wait_each", [False, True])
+def test_host_pushes_of_every_transport_mix_and_no_result_is_stranded(dev, wait_each):
+    """dn_pipe_stream_push_host with the transports mixed on one pipe -- deferred, direct and staged pushes in turn, each into its own page-locked
+    buffer -- and dn_pipe_stream_host_wait either on every push at once (the wait on the NEWEST deferred push has to enqueue the move of its
+    samples itself: no later launch will) or only at the end, newest first.  Every push's buffer must hold what the device-fed stream emitted."""
+    import ctypes as C
+    from audio_denoising_amd import _lib
+    from audio_denoising_amd.pipeline import Denoiser, PipelinedStream
+    p = _params("S")
+    B, n = 37, 10
+    dn = Denoiser(_model(dev, 5), p.sample_rate, p.n_fft, p.hop, p.n_mels)
+    g = torch.Generator().manual_seed(77)
+    host = ((0.3 * torch.randn(B, n * p.hop, generator=g)).clamp(-1, 1) * 32767.0).to(torch.int16)
+    hops = [host[:, i * p.hop:(i + 1) * p.hop].contiguous().pin_memory() for i in range(n)]
+    ref = PipelinedStream(dn, B, seed=4, stream_id0=9)
+    want = [ref.push(h.to(dev)).cpu() for h in hops]
+    ps = PipelinedStream(dn, B, seed=4, stream_id0=9)
+    D, Z, S = _lib.DN_HOST_DEFER, 0, _lib.DN_HOST_STAGED
+    flags = [D, D, Z, D, S, D, D, Z, S, D]
+    outs = [torch.full((B, p.hop), -7, dtype=torch.int16).pin_memory() for _ in range(n)]
+    tickets = []
+    with torch.cuda.device(dev):
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for i in range(n):
+            t = C.c_uint64()
+            ps.lib.check(ps.lib.dn_pipe_stream_push_host(ps.handle, hops[i].data_ptr(), 1, outs[i].data_ptr(), 1, 4, 9, dn.n_iter, dn.momentum,
+                                                         flags[i], st, C.byref(t)))
+            tickets.append(t.value)
+            if wait_each:
+                ps.lib.check(ps.lib.dn_pipe_stream_host_wait(ps.handle, t.value))
+                assert torch.equal(outs[i], want[i]), f"push {i}"
+        assert tickets == list(range(n))
+        for i in reversed(range(n)):
+            ps.lib.check(ps.lib.dn_pipe_stream_host_wait(ps.handle, tickets[i]))
+            assert torch.equal(outs[i], want[i]), f"push {i}"
+    assert any(w.any() for w in want)
+    assert torch.equal(ps.flush(s16=True).cpu(), ref.flush(s16=True).cpu())
 
 
 def test_app_parameters_refuse_the_schedules_built_for_n_fft_1024(dev):

@@ -15,10 +15,13 @@ run --batch 1024
 run --batch 4096
 run --batch 8192
 run --stream --batch 256 --depth 4
-run --stream --pcie --batch 256 --steps 2000          # host-fed (zero copy from page-locked memory)
+run --stream --depth 1 --batch 256                    # (device-fed at depth 1 and at 1,024 streams without the graph: what the host-fed lines compare with)
+run --stream --batch 1024
+run --stream --pcie --batch 256 --steps 2000          # host-fed (zero copy from page-locked memory; the emitted hop leaves with the next launch)
 run --stream --pcie --batch 256 --depth 4 --steps 2000
 run --stream --pcie --batch 1024 --steps 1000
-DN_HOST_STAGED=1 run --stream --pcie --batch 1024 --steps 1000
+DN_HOST_DIRECT=1 run --stream --pcie --batch 1024 --steps 1000     # ... stored straight to host memory by its own launch
+DN_HOST_STAGED=1 run --stream --pcie --batch 1024 --steps 1000     # ... through staging buffers on two copy queues
 run --preset R1
 run --preset R1 --batch 1024
 run --preset R2
