@@ -32,6 +32,7 @@
 
 struct float2 { float x, y; };
 struct float4 { float x, y, z, w; };
+struct uint4 { unsigned int x, y, z, w; };
 inline float2 make_float2(float x, float y) { return float2{x, y}; }
 inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 
@@ -67,7 +68,12 @@ inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
 // pointer attributes: everything is "host pageable" here, so the staged path of dn_pipe_stream_push_host is what the emulation runs
 enum hipMemoryType { hipMemoryTypeHost, hipMemoryTypeDevice, hipMemoryTypeUnregistered };
 struct hipPointerAttribute_t { hipMemoryType type; };
-inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void*) { a->type = hipMemoryTypeUnregistered; return 0; }
+// DN_EMU_PINNED=1 (set by a test around its calls): every host pointer counts as page-locked, so the zero-copy transports can be emulated
+inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void*) {
+    const char* e = getenv("DN_EMU_PINNED");
+    a->type = (e && e[0] == '1') ? hipMemoryTypeHost : hipMemoryTypeUnregistered;
+    return 0;
+}
 inline hipError_t hipHostGetDevicePointer(void** d, void* h, unsigned) { *d = h; return 0; }
 inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { *p = malloc(n); return *p ? 0 : 1; }
 inline hipError_t hipHostFree(void* p) { free(p); return 0; }

@@ -244,6 +244,47 @@ def test_streaming_pipe_matches_oracle_with_one_hop_delay(lib, dsp):
     lib.dn_model_destroy(m)
 
 
+def test_host_transports_emit_the_device_fed_samples(lib, dsp, monkeypatch):
+    """dn_pipe_stream_push_host on the emulator: staged (pageable buffers), zero copy direct and zero copy deferred (DN_HOST_DEFER: the next
+    launch carries the samples out; a wait on the newest push moves them itself), mixed on one pipe, against dn_pipe_stream_push.  The
+    emulated runtime calls a pointer page-locked when DN_EMU_PINNED=1."""
+    from audio_denoising_amd import _lib
+    g = load_golden("stream_S.npz")
+    B, n, n_iter = 3, 7, 2
+    m = make_model(lib, 5)
+    hops = [np.ascontiguousarray(np.clip(g["signal"][:B, h * P.hop:(h + 1) * P.hop] * 32767.0, -32767, 32767).astype(np.int16)) for h in range(n)]
+    ref = C.c_void_p()
+    lib.check(lib.dn_pipe_stream_create(m, dsp, B, 0, C.byref(ref)))
+    want = []
+    for h in hops:
+        o = np.zeros((B, P.hop), np.int16)
+        lib.check(lib.dn_pipe_stream_push(ref, emu.ptr(h), 1, emu.ptr(o), 1, None, 11, 3, n_iter, 0.99, None))
+        want.append(o)
+    lib.dn_pipe_destroy(ref)
+    assert any(w.any() for w in want)
+    D, Z, S = _lib.DN_HOST_DEFER, 0, _lib.DN_HOST_STAGED
+    for flags, wait_each in (([D, D, Z, D, S, D, D], False), ([D, D, D, Z, S, Z, D], True)):
+        pipe = C.c_void_p()
+        lib.check(lib.dn_pipe_stream_create(m, dsp, B, 0, C.byref(pipe)))
+        outs = [np.full((B, P.hop), -7, np.int16) for _ in range(n)]
+        for i in range(n):
+            monkeypatch.setenv("DN_EMU_PINNED", "0" if flags[i] == S else "1")
+            t = C.c_uint64()
+            lib.check(lib.dn_pipe_stream_push_host(pipe, emu.ptr(hops[i]), 1, emu.ptr(outs[i]), 1, 11, 3, n_iter, 0.99, flags[i], None, C.byref(t)))
+            assert t.value == i
+            if flags[i] == D and not wait_each:
+                assert np.all(outs[i] == -7)                     # still in the staging buffer
+            if wait_each:
+                lib.check(lib.dn_pipe_stream_host_wait(pipe, i))
+                assert np.array_equal(outs[i], want[i]), f"push {i}"
+        for i in reversed(range(n)):
+            lib.check(lib.dn_pipe_stream_host_wait(pipe, i))
+            assert np.array_equal(outs[i], want[i]), f"push {i}"
+        assert lib.dn_pipe_stream_host_wait(pipe, n) != 0        # no such push
+        lib.dn_pipe_destroy(pipe)
+    lib.dn_model_destroy(m)
+
+
 # ------------------------------------------------------------------ the app's own parameters: n_fft 1536 (768 = 4*4*4*12)
 P1 = pipeline_ref.PARAMS_R1
 
