@@ -125,12 +125,6 @@ __global__ __launch_bounds__(kHopPipeThreads, (NFFT == 1536 || GLW) ? 2 : 1) voi
     const unsigned int pending = a.ctl->pending, slot_next = a.ctl->slot_next;
     const SlotLayout sl(a.B, d.n_mels, kBins);
     const bool priming = STREAM && pushes < (unsigned long long)a.prime;
-    if (STREAM && a.host_copy_src != nullptr) {
-        // the previous push's emitted hop: device staging buffer -> its page-locked host buffer (every thread of the grid, before the roles part:
-        // the stores are posted and drain while the hop computes; the last workgroup's system-scope fence below covers them)
-        for (unsigned int u = blockIdx.x * kHopPipeThreads + tid; u < a.host_copy_n16; u += gridDim.x * kHopPipeThreads)
-            a.host_copy_dst[u] = a.host_copy_src[u];
-    }
 #ifdef DN_PROBE
     if (tid == 0 && blockIdx.x < 2048) {
         unsigned int hw, xcc;
@@ -239,6 +233,14 @@ __global__ __launch_bounds__(kHopPipeThreads, (NFFT == 1536 || GLW) ? 2 : 1) voi
         DN_HSTAMP(2);
         const float* frames_in = a.frames;
         if (STREAM) {
+            if (__builtin_expect(a.host_copy_src != nullptr, 0)) {
+                // deferred host output: the hop the PREVIOUS push emitted for this stream, device staging buffer -> its page-locked host buffer.
+                // The front workgroups of a launch start all through it, so the posted stores drain while the hop computes instead of ending the
+                // previous launch as one PCIe burst; the last workgroup's system-scope fence below covers them.  (Here and not at the head of the
+                // kernel: there the same lines cost the chain waves of EVERY streaming launch 2 % -- 155.8 -> 159.2 us at 1,024 streams.)
+                const unsigned int per = a.host_copy_n16 / (unsigned int)a.B;          // 16-byte units of one stream's hop
+                for (unsigned int i = tid; i < per; i += kHopPipeThreads) a.host_copy_dst[b * per + i] = a.host_copy_src[b * per + i];
+            }
             ring_shift<NFFT, kHopPipeThreads>(a.ring, a.hop_in, a.in_s16, b, tid);
             frames_in = a.ring;
         }

@@ -163,9 +163,9 @@ struct HopArgs {
     // zero-copy host transport: hop_in / hop_out are page-locked HOST memory; the last workgroup of the launch, after every workgroup's stores have
     // been fenced to system scope, publishes host_done_value in *host_done (page-locked too) -- the host polls that word instead of a HIP event
     unsigned long long* host_done; unsigned long long host_done_value;
-    // deferred host output (DN_HOST_DEFER): the hop the PREVIOUS push emitted sits in a device staging buffer; every thread of this launch moves
-    // its share of it (16-byte units, grid stride) to that push's page-locked buffer before anything else, so the PCIe writes overlap the hop
-    // instead of ending it as one burst (null = nothing to move)
+    // deferred host output (DN_HOST_DEFER): the hop the PREVIOUS push emitted sits in a device staging buffer; the front workgroup of stream b
+    // moves that stream's row (host_copy_n16 / B 16-byte units) to that push's page-locked buffer before it starts on its own hop, so the PCIe
+    // writes overlap the hop instead of ending it as one burst (null = nothing to move; only launches with front workgroups carry one)
     const uint4* host_copy_src; uint4* host_copy_dst; unsigned int host_copy_n16;
 };
 void launch_host_copy(const uint4* src, uint4* dst, unsigned int n16, unsigned long long* done, unsigned long long value, hipStream_t st);

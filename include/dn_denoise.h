@@ -321,7 +321,7 @@ int dn_pipe_stream_flush(dn_pipe* p, void* hop_out, int32_t out_is_s16, int32_t 
  * with four sets in rotation the host can stay two pushes ahead of the result it waits for, which keeps the GPU busy back to back).  Initial phases
  * come from the device generator; mix freely with dn_pipe_stream_push / _flush on the same `stream`.
  *   flags = DN_HOST_DEFER (zero copy only; ignored otherwise): the launch leaves its emitted hop in a device staging buffer and the NEXT push's
- *   launch moves it to hop_out_host, every thread a 16-byte share, before it starts on its own hop -- the PCIe writes then overlap a hop's
+ *   launch moves it to hop_out_host, each front workgroup its stream's row before it starts on its own hop -- the PCIe writes then overlap a hop's
  *   arithmetic instead of ending the launch as one burst (1,024 streams: 2 MB in 14 us of a 170 us launch).  The samples of push i are in host
  *   memory once push i + 1 has run; dn_pipe_stream_host_wait on the NEWEST push enqueues the move itself (on the stream of that push), so no
  *   result is ever stranded.  Same samples, one push later: for a host that stays ahead of the results it waits for, not for the lowest latency.
