@@ -301,14 +301,22 @@ class PipelinedStream(_Pipe):
     def graph_step(self, hop: torch.Tensor, out: torch.Tensor, init_angles: torch.Tensor | None = None) -> "torch.cuda.CUDAGraph":
         """Capture ONE push into a hipGraph (BASELINE config 5: the hipGraph-captured step).  Replaying it is a push of
         whatever ``hop`` (and ``init_angles``, parity mode) hold at that moment into ``out``; it can be replayed
-        indefinitely and mixed with eager pushes."""
+        indefinitely and mixed with eager pushes.  ``hop`` / ``out`` of shape ``(K, B, hop_length)`` capture K consecutive pushes
+        (hop k into out k) as ONE graph: a replay then costs one graph launch per K hops (a graph launch leaves ~5 us of idle
+        GPU behind it where eager launches run back to back)."""
         self._bind()
         if init_angles is not None:
             # the slot buffers for injected phases are allocated by the first parity-mode launch: do that outside the capture
             self._warm_parity()
+        if hop.dim() == 3 and (out.dim() != 3 or out.shape[0] != hop.shape[0] or (init_angles is not None and init_angles.shape[0] != hop.shape[0])):
+            raise ValueError("K hops need K outputs (and K sets of init_angles)")
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            self.push_(hop, out, init_angles, check_weights=False)
+            if hop.dim() == 3:
+                for k in range(hop.shape[0]):
+                    self.push_(hop[k], out[k], None if init_angles is None else init_angles[k], check_weights=False)
+            else:
+                self.push_(hop, out, init_angles, check_weights=False)
         return g
 
     def _warm_parity(self) -> None:

@@ -186,6 +186,20 @@ def extra_measurements(args, dev, budget_steps=1500):
     el = time.perf_counter() - t0
     res["config5_stream_graph_1024"] = {"value": round(B5 * n5 / el, 1), "unit": "frames/s", "ms_per_step": round(1e3 * el / n5, 4), "streams": B5,
                                         "mode": "dn_pipe_stream_push captured once in a hipGraph, replayed per hop; ring/overlap-add/hx resident"}
+    # the same with eight consecutive pushes captured as ONE graph (a graph launch leaves ~5 us of idle GPU behind it; eager launches do not)
+    K8 = 8
+    hops8 = (0.1 * torch.randn(K8, B5, dn.hop, generator=g)).to(dev)
+    outs8 = torch.empty_like(hops8)
+    graph8 = ps.graph_step(hops8, outs8)
+    prewarm(graph8.replay)
+    t0 = time.perf_counter()
+    for _ in range(n5 // K8):
+        graph8.replay()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    ps.flush()
+    res["config5_stream_graph_1024"]["graph_of_8_hops"] = {"value": round(B5 * (n5 // K8) * K8 / el, 1), "unit": "frames/s",
+                                                           "ms_per_step": round(1e3 * el / ((n5 // K8) * K8), 4)}
     # saturated regime (wavefront-per-stream Griffin-Lim)
     for b, n in ((1024, 300), (8192, 40)):
         v, ms = time_pipe(dn, b, dev, n, 1)
@@ -316,11 +330,17 @@ def side_measurement(args, dn, B, dev):
         mode = "stream"
         if args.graph:
             # BASELINE config 5: ONE hipGraph-captured push replayed per hop (slot parity / seed / pending live on the device)
+            gk = max(1, args.graph_hops)
+            if gk > 1:
+                hop = (0.1 * torch.randn(gk, B, dn.hop, generator=g)).to(dev)
+                hop_out = torch.empty_like(hop)
             graph = ps.graph_step(hop, hop_out)
-            mode = "stream+hipGraph"
+            mode = "stream+hipGraph" + (f" ({gk} pushes per graph)" if gk > 1 else "")
+            args.steps = max(1, args.steps // gk) * gk
 
             def step(i):
-                graph.replay()
+                if i % gk == 0:
+                    graph.replay()
         else:
             def step(i):
                 ps.push_(hop, hop_out, check_weights=False)
@@ -502,6 +522,7 @@ def main():
     ap.add_argument("--pcie", action="store_true", help="side measurement: frames arrive in pinned host memory and results return to it every hop")
     ap.add_argument("--stream", action="store_true", help="streaming mode (BASELINE config 5): pipe-owned ring/overlap-add/hx state, one hop of new samples per step")
     ap.add_argument("--graph", action="store_true", help="with --stream: replay ONE hipGraph-captured push per step")
+    ap.add_argument("--graph-hops", type=int, default=1, help="with --stream --graph: consecutive pushes captured per graph")
     ap.add_argument("--depth", type=int, default=0, help="hops of one stream in flight (dn_pipe_set_depth, 1..4); 0 = the throughput default for the batch "
                                                             "(4 up to 384 streams, 2 below 768, else 1); 1 = output after the next hop")
     ap.add_argument("--no-extras", action="store_true", help="skip the bounded side measurements carried in the line (config 3, config 5, R1, batch-1 latency)")

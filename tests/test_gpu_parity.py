@@ -1340,6 +1340,33 @@ def test_app_parameters_refuse_the_schedules_built_for_n_fft_1024(dev):
     pipe.set_depth(1)
 
 
+def test_several_pushes_captured_as_one_graph_replay(dev):
+    """`PipelinedStream.graph_step` with (K, B, hop) tensors: K consecutive pushes captured as ONE hipGraph (one graph launch per K hops).  Four
+    replays of a three-push graph equal twelve eager pushes bit for bit."""
+    from audio_denoising_amd.pipeline import Denoiser, PipelinedStream
+    p = _params("S")
+    B, K = 64, 3
+    dn = Denoiser(_model(dev, 5), p.sample_rate, p.n_fft, p.hop, p.n_mels)
+    g = torch.Generator().manual_seed(6)
+    sig = (0.3 * torch.randn(B, 12 * p.hop, generator=g)).clamp(-1, 1).to(dev)
+    eager = PipelinedStream(dn, B, seed=3)
+    a = torch.cat([eager.push(sig[:, i * p.hop:(i + 1) * p.hop].contiguous()) for i in range(12)] + [eager.flush()], 1)
+    ps = PipelinedStream(dn, B, seed=3)
+    hops = torch.empty(K, B, p.hop, device=dev)
+    outs = torch.empty(K, B, p.hop, device=dev)
+    step = ps.graph_step(hops, outs)
+    res = []
+    for r in range(4):
+        for k in range(K):
+            hops[k].copy_(sig[:, (r * K + k) * p.hop:(r * K + k + 1) * p.hop])
+        step.replay()
+        res += [outs[k].clone() for k in range(K)]
+    b = torch.cat(res + [ps.flush()], 1)
+    assert torch.equal(a, b) and a.abs().max().item() > 1e-3
+    with pytest.raises(ValueError):
+        ps.graph_step(hops, outs[0])
+
+
 def test_captured_push_of_a_deep_pipe_replays(dev):
     """BASELINE config 5's captured step on a deep pipe: ONE hipGraph-captured dn_pipe_stream_push at depth 4 (which chain segment of which hop a
     wavefront runs is decided from the device-resident control block, nothing hop-dependent is baked into the launch) replayed twelve times equals

@@ -9,6 +9,7 @@ run --depth 3
 run --serial                          # one launch per hop, no added latency
 run --conv bf16                       # BASELINE config 3
 run --stream --graph --batch 1024     # BASELINE config 5 under hipGraph replay
+run --stream --graph --graph-hops 8 --batch 1024 --steps 400      # ... eight pushes per captured graph
 run --batch 512
 run --batch 768
 run --batch 1024
