@@ -172,6 +172,7 @@ struct dn_pipe {
     size_t slot_floats = 0, init_elems = 0, state_elems = 0;
     int gl_split = 0;                               // iterations of head start (0 = none)
     int gl_schedule = DN_GL_AUTO;                   // Griffin-Lim schedule of the back half (dn_pipe_set_gl_schedule)
+    int split = DN_SPLIT_AUTO;                      // a hop as two launches, chains then front halves (dn_pipe_set_split)
     BiasSet* bs = nullptr;
     bool submitted = false;                   // frame mode: a hop may be pending (its destination travels in the slot, not here)
     // streaming mode: per-stream state owned by the pipe
@@ -994,6 +995,15 @@ int dn_pipe_set_gl_schedule(dn_pipe* p, int32_t schedule) {
     return DN_OK;
 }
 
+int dn_pipe_set_split(dn_pipe* p, int32_t mode) {
+    if (!p) return fail(DN_ERR_INVALID, "dn_pipe_set_split: null pipe");
+    if (mode != DN_SPLIT_AUTO && mode != DN_SPLIT_OFF && mode != DN_SPLIT_ON) return fail(DN_ERR_INVALID, "dn_pipe_set_split: unknown mode");
+    if (mode == DN_SPLIT_ON && p->d->cfg.n_fft != 1024)
+        return fail(DN_ERR_UNSUPPORTED, "the split hop belongs to the wavefront-per-stream Griffin-Lim, which is built for n_fft 1024");
+    p->split = mode;
+    return DN_OK;
+}
+
 int dn_pipe_set_model(dn_pipe* p, const dn_model* m) {
     if (!p || !m) return fail(DN_ERR_INVALID, "dn_pipe_set_model: null argument");
     if (m == p->m) return DN_OK;
@@ -1088,6 +1098,10 @@ static int fill_hop_args(dn_pipe* p, dn::HopArgs& a, const float* init_angles, u
     a.depth = p->depth;
     a.spb = per_stream ? 4 / p->depth : 1;          // a workgroup is four wavefronts: streams x chain segments
     a.back_blocks = (p->B + a.spb - 1) / a.spb;
+    // two launches per hop where the chip holds only a fraction of a launch's workgroups at once (its chains and its front halves then run as
+    // two phases anyway): from dn::kSplitAutoChains chain wavefronts on -- 2,048 fill every SIMD of an MI355X twice
+    const bool can_split = per_stream && p->gl_split == 0;
+    a.split = can_split && (p->split == DN_SPLIT_ON || (p->split == DN_SPLIT_AUTO && (long)p->B * p->depth >= dn::kSplitAutoChains)) ? 1 : 0;
     a.prime = p->d->cfg.n_fft / p->d->cfg.hop - 1;
     return DN_OK;
 }

@@ -437,7 +437,15 @@ struct CellStager {
 // CT = the number of compressed bins when it is known at compile time (5: 80 mels, 4: 64 mels), 0 = use the run-time value.
 // With CT every length, stride and item/length division of the conv tiles is a constant: the per-k-step address arithmetic
 // (which, not the MFMAs, was what a phase spent its issue slots on) folds into immediate LDS offsets.
-template <int NW, bool BF16 = false, int CT = 0>
+// STAGE = false: every level reads its fragments and bias table straight from L2 -- no staging loads, no LDS copies, 35 KB of LDS instead of 74
+// (kCellSmemUnstaged): what lets FOUR front workgroups share a CU when they run as a launch of their own (dn_hop.hip, FRONT).
+#ifdef DN_CELL_NOSTAGE
+constexpr bool kCellStageDefault = false;
+#else
+constexpr bool kCellStageDefault = true;
+#endif
+constexpr int kCellSmemUnstaged = 4 * kCellActFloats;
+template <int NW, bool BF16 = false, int CT = 0, bool STAGE = kCellStageDefault>
 __device__ __forceinline__ void cell_body(char* smem, const CellDev& cd, const float* __restrict__ x,
                                           const float* __restrict__ hx_in, float* __restrict__ out,
                                           float* __restrict__ hx_out, int T, int C_rt, size_t b, int tid,
@@ -477,18 +485,11 @@ __device__ __forceinline__ void cell_body(char* smem, const CellDev& cd, const f
     // two register sets: level L+2 is requested while level L multiplies and level L+1 (requested a phase earlier) is dropped
     // into its buffer -- every request has more than a whole phase to come back from L2
     CellStager<kCellThreads, CT != 0 && kCellThreads == 256> stgA, stgB;
-    // (experiment knob DN_CELL_NOSTAGE: every level reads its fragments and bias table straight from L2 -- no staging loads, no LDS copies)
-#ifdef DN_CELL_NOSTAGE
-#define DN_STG_ISSUE(s, i) do { } while (0)
-#define DN_STG_COMMIT(s, i) do { } while (0)
-#define DN_LW(i) level(i).w
-#define DN_LB(i) level(i).b
-#else
-#define DN_STG_ISSUE(s, i) s.issue(level(i), tid)
-#define DN_STG_COMMIT(s, i) s.commit(level(i), wbuf[(i) & 1], bbuf[(i) & 1], tid)
-#define DN_LW(i) wbuf[(i) & 1]
-#define DN_LB(i) bbuf[(i) & 1]
-#endif
+    // (build knob DN_CELL_NOSTAGE flips the default of STAGE)
+#define DN_STG_ISSUE(s, i) do { if constexpr (STAGE) s.issue(level(i), tid); } while (0)
+#define DN_STG_COMMIT(s, i) do { if constexpr (STAGE) s.commit(level(i), wbuf[(i) & 1], bbuf[(i) & 1], tid); } while (0)
+#define DN_LW(i) (STAGE ? static_cast<const float*>(wbuf[(i) & 1]) : level(i).w)
+#define DN_LB(i) (STAGE ? static_cast<const float*>(bbuf[(i) & 1]) : level(i).b)
     DN_STG_ISSUE(stgA, 0);
     DN_STG_ISSUE(stgB, 1);
 

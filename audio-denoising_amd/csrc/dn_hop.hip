@@ -37,6 +37,7 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 template <int NFFT> constexpr int hop_smem() {
     return cmax(cmax(cmax(kCellSmem, gl_smem<NFFT>()), cmax(stft_smem<NFFT>(), kInvSmem)), NFFT == 1024 ? glw_smem<1024>() : 0);
 }
+template <int NFFT> constexpr int front_smem() { return cmax(cmax(kCellSmemUnstaged, stft_smem<NFFT>()), kInvSmem); }    // 35 KB: four a CU
 static_assert(kHopThreads == kGlThreads && kHopThreads == kStftThreads && kHopThreads == kInvThreads, "one block size for all bodies");
 
 // ring <- concat(ring[hop:], hop_in): every thread holds its float4s before anything is overwritten   (app3.py:174,226)
@@ -115,10 +116,16 @@ __device__ __forceinline__ int slot_behind(unsigned int slot_next, int back, int
 //                 about one stream per CU this is what fills the CU -- throughput of the saturated regime at batch 256 for D - 1 more
 //                 hops of latency.
 //      Capped at two waves per SIMD.
-template <int NFFT, bool STREAM, bool BF16, int CT, bool GLW>
-__global__ __launch_bounds__(kHopPipeThreads, (NFFT == 1536 || GLW) ? 2 : 1) void hop_kernel(DspDev d, CellDev cd, HopArgs a) {
+// FRONT: a launch of front workgroups only, the second of the TWO launches of a split hop (a.front_only; the first is this kernel's
+//      ordinary form with front_B = 0: the chains).  Where a launch carries many more workgroups than the chip holds at once, its Griffin-Lim
+//      workgroups (the low block ids) run first and its front workgroups after them anyway -- two phases, not a mix -- and a front workgroup
+//      compiled beside the chain inherits the chain's 243 registers: two workgroups a CU.  On its own the front half is capped at
+//      kFrontPerCu workgroups a CU (its phases end at workgroup barriers and wait on memory: more of them in flight is what it wants).
+constexpr int kFrontPerCu = 4;
+template <int NFFT, bool STREAM, bool BF16, int CT, bool GLW, bool FRONT = false>
+__global__ __launch_bounds__(kHopPipeThreads, FRONT ? kFrontPerCu : (NFFT == 1536 || GLW) ? 2 : 1) void hop_kernel(DspDev d, CellDev cd, HopArgs a) {
     constexpr int kNR = NFFT, kBins = Geo<NFFT>::kBins;
-    __shared__ __attribute__((aligned(16))) char smem[hop_smem<NFFT>()];
+    __shared__ __attribute__((aligned(16))) char smem[FRONT ? front_smem<NFFT>() : hop_smem<NFFT>()];
     const int tid = threadIdx.x;
     // control block as the previous launch left it (uniform: scalar loads)
     const unsigned long long pushes = a.ctl->pushes, frames = a.ctl->frames, launches = a.ctl->launches;
@@ -138,9 +145,9 @@ __global__ __launch_bounds__(kHopPipeThreads, (NFFT == 1536 || GLW) ? 2 : 1) voi
 #endif
     // the oldest frame in flight completes in this launch when this is its last segment (wavefront per column: depth 1, always)
     const int depth = GLW ? a.depth : 1;
-    const bool completes = pending > 0 && launches - a.ctl->front_launch[(frames - pending) & 7] == (unsigned long long)depth;
-    if (GLW && (int)blockIdx.x < a.back_blocks) {
-        if constexpr (GLW) {
+    const bool completes = !FRONT && pending > 0 && launches - a.ctl->front_launch[(frames - pending) & 7] == (unsigned long long)depth;
+    if (!FRONT && GLW && (int)blockIdx.x < a.back_blocks) {
+        if constexpr (GLW && !FRONT) {
             const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
             const int sidx = wv / depth, j = wv - sidx * depth;          // stream of the workgroup, frames behind the newest (uniform)
             const size_t b = (size_t)blockIdx.x * a.spb + sidx;
@@ -191,7 +198,8 @@ __global__ __launch_bounds__(kHopPipeThreads, (NFFT == 1536 || GLW) ? 2 : 1) voi
                 }
             }
         }
-    } else if ((int)blockIdx.x < a.back_blocks) {
+    } else if (!FRONT && (int)blockIdx.x < a.back_blocks) {
+      if constexpr (!FRONT) {
         const size_t b = blockIdx.x;
         if (tid >= kHopThreads) return;         // (before any barrier: a terminated wave no longer counts at s_barrier)
         DN_HSTAMP(0);
@@ -228,8 +236,9 @@ __global__ __launch_bounds__(kHopPipeThreads, (NFFT == 1536 || GLW) ? 2 : 1) voi
                 else static_cast<float*>(a.hop_out)[b * (kNR / 2) + n] = 0.0f;
             }
         }
+      }
     } else {
-        const size_t b = blockIdx.x - a.back_blocks;
+        const size_t b = blockIdx.x - (FRONT ? 0 : a.back_blocks);
         DN_HSTAMP(2);
         const float* frames_in = a.frames;
         if (STREAM) {
@@ -249,7 +258,7 @@ __global__ __launch_bounds__(kHopPipeThreads, (NFFT == 1536 || GLW) ? 2 : 1) voi
             float* slot = a.slots + (size_t)s * a.slot_stride;
             float2* slot_init = a.slot_init + (size_t)s * a.init_stride;
             stft_body<NFFT, false, true, kHopPipeThreads>(smem, d, frames_in, nullptr, slot, slot + sl.peak, DN_PEAK_NORMALIZE | DN_PRE_WINDOW, b, tid);   // P1-P6
-            const int split = min(a.gl_split, a.n_iter);
+            const int split = FRONT ? 0 : min(a.gl_split, a.n_iter);        // (a split hop has no head start)
             // (measured: n_fft 1536, 13 bins a lane: 106 -> 100 us per batch-256 hop; n_fft 1024, 9 bins a lane: 54.7 -> 55.2 us -- the draw's 12 KB
             // a stream through HBM cost more than the multiplies it moved off the chain, so only the long transform uses it)
             // A deep pipe (a.depth > 1: the chain runs as segments, one wavefront per stream) draws here too, at either transform length: there the
@@ -271,7 +280,7 @@ __global__ __launch_bounds__(kHopPipeThreads, (NFFT == 1536 || GLW) ? 2 : 1) voi
             }
             __syncthreads();
             DN_HSTAMP(5);
-            cell_body<kHopPipeThreads / 64, BF16, CT>(smem, cd, slot, a.hx, slot + sl.diff, a.hx, 3, a.C, b, tid);                        // P7
+            cell_body<kHopPipeThreads / 64, BF16, CT, FRONT ? false : kCellStageDefault>(smem, cd, slot, a.hx, slot + sl.diff, a.hx, 3, a.C, b, tid);   // P7
             __syncthreads();
             DN_HSTAMP(6);
             invmel_body<NFFT, true, kHopPipeThreads>(smem, d, slot, slot + sl.diff, slot + sl.lin, 3 * a.B, b * 3, tid);                  // P8-P10
@@ -297,7 +306,7 @@ __global__ __launch_bounds__(kHopPipeThreads, (NFFT == 1536 || GLW) ? 2 : 1) voi
                 float2* dst = slot_init + b * 3 * kBins;
                 for (int i = tid; i < 3 * kBins; i += kHopPipeThreads) dst[i] = src[i];
             }
-            if (split > 0) {
+            if constexpr (!FRONT) if (split > 0) {
                 // head start: this workgroup would idle for the rest of the launch (the pending hop's chain is ~1.5x longer than P1-P10)
                 __syncthreads();                       // the magnitudes are in the slot
                 if (tid >= kHopThreads) return;        // the chain is three waves wide
@@ -326,11 +335,11 @@ __global__ __launch_bounds__(kHopPipeThreads, (NFFT == 1536 || GLW) ? 2 : 1) voi
         const unsigned int t = atomicAdd(&a.ctl->done, 1u);
         if (t == gridDim.x - 1) {
             a.ctl->done = 0;
-            a.ctl->launches = launches + 1;
+            if (!FRONT) a.ctl->launches = launches + 1;     // (the chains' launch of a split hop has counted it: this one is launch `launches - 1` still)
             const bool fronted = a.front_B > 0 && !priming;
             if (a.front_B > 0) a.ctl->pushes = pushes + 1;
             if (fronted) {
-                a.ctl->front_launch[frames & 7] = launches;
+                a.ctl->front_launch[frames & 7] = FRONT ? launches - 1 : launches;
                 a.ctl->frames = frames + 1;
                 a.ctl->slot_next = (int)slot_next + 1 == a.n_slots ? 0u : slot_next + 1;
             }
@@ -345,8 +354,22 @@ __global__ __launch_bounds__(kHopPipeThreads, (NFFT == 1536 || GLW) ? 2 : 1) voi
 
 template <int NFFT, bool STREAM, bool GLW>
 static void launch_hop_n(const DspDev& d, const CellDev& c, const HopArgs& a, bool bf16, hipStream_t st) {
-    const dim3 grid(a.back_blocks + a.front_B), block(kHopPipeThreads);
+    const dim3 block(kHopPipeThreads);
     constexpr int kUsualC = NFFT == 1536 ? 4 : 5;
+    if constexpr (GLW) {
+        if (a.front_only) {             // the second launch of a split hop: front workgroups alone, under their own register budget
+            const dim3 fgrid(a.front_B);
+            if (a.C == kUsualC) {
+                if (bf16) hipLaunchKernelGGL((hop_kernel<NFFT, STREAM, true, kUsualC, true, true>), fgrid, block, 0, st, d, c, a);
+                else hipLaunchKernelGGL((hop_kernel<NFFT, STREAM, false, kUsualC, true, true>), fgrid, block, 0, st, d, c, a);
+            } else {
+                if (bf16) hipLaunchKernelGGL((hop_kernel<NFFT, STREAM, true, 0, true, true>), fgrid, block, 0, st, d, c, a);
+                else hipLaunchKernelGGL((hop_kernel<NFFT, STREAM, false, 0, true, true>), fgrid, block, 0, st, d, c, a);
+            }
+            return;
+        }
+    }
+    const dim3 grid(a.back_blocks + a.front_B);
     if (a.C == kUsualC) {
         if (bf16) hipLaunchKernelGGL((hop_kernel<NFFT, STREAM, true, kUsualC, GLW>), grid, block, 0, st, d, c, a);
         else hipLaunchKernelGGL((hop_kernel<NFFT, STREAM, false, kUsualC, GLW>), grid, block, 0, st, d, c, a);
@@ -373,6 +396,16 @@ void launch_host_copy(const uint4* src, uint4* dst, unsigned int n16, unsigned l
 
 void launch_hop(const DspDev& d, const CellDev& c, const HopArgs& a, bool bf16, hipStream_t st) {
     const bool stream = a.ola != nullptr;
+    if (a.split && a.glw && a.front_B > 0 && d.n_fft == 1024) {
+        // a split hop: the chains of the hops in flight first (this launch is what a flush launch is), then the new hop's front halves
+        HopArgs chains = a, fronts = a;
+        chains.split = 0; chains.front_B = 0;
+        chains.host_done = nullptr; chains.host_copy_src = nullptr;          // (the transport belongs to the launch that ends the hop)
+        fronts.split = 0; fronts.front_only = 1; fronts.back_blocks = 0; fronts.gl_split = 0;
+        launch_hop(d, c, chains, bf16, st);
+        launch_hop(d, c, fronts, bf16, st);
+        return;
+    }
     if (d.n_fft == 1536) {
         if (stream) launch_hop_n<1536, true, false>(d, c, a, bf16, st);
         else launch_hop_n<1536, false, false>(d, c, a, bf16, st);

@@ -103,7 +103,8 @@ constexpr int kMaxC = 5;         // compressed bins supported by the cell kernel
 constexpr int mel_q_steps(int n_fft) { return n_fft == 1536 ? 48 : 32; }
 constexpr int kInvBand = 16;      // diagonals of (fb^T fb)^-1 kept on either side of the main one (DspDev::ginv_band)
 constexpr int kSlotMeta = 16;     // u32 of per-stream hand-over data in a pipe's scratch slot (dn_hop.hip: SlotLayout)
-constexpr int kGlwAutoStreams = 768;   // DN_GL_AUTO: from this many streams per pipe on (three per CU of an MI355X; measured crossover between 512 and 768) the back half runs a wavefront per stream
+constexpr int kGlwAutoStreams = 768;
+constexpr long kSplitAutoChains = 4096;         // DN_SPLIT_AUTO: chain wavefronts per launch from which a hop goes out as two launches (measured: 2,048 -2.4 %, 4,096 +2.1 %, 8,192 +5.1 %)   // DN_GL_AUTO: from this many streams per pipe on (three per CU of an MI355X; measured crossover between 512 and 768) the back half runs a wavefront per stream
 constexpr int kArenaSlack = 8192; // zero bytes behind every device arena: kernels that move whole rounds of an array read past its end (dn_cell_body.hpp)
 
 void launch_stft(const DspDev& d, const float* frames, float* spec, float* mel, float* peak, int B, uint32_t flags,
@@ -156,6 +157,8 @@ struct HopArgs {
     // back half: back_blocks workgroups.  A wavefront per column: back_B of them, one pending hop.  A wavefront per stream (dn_glw_body.hpp): each
     // holds spb streams x depth chain segments (spb x depth <= 4), back_blocks = ceil(back_B / spb)
     int back_blocks, spb, depth, glw;
+    // split: the hop goes out as two launches (launch_hop does that: chains, then front halves); front_only marks the second of them
+    int split, front_only;
     // streaming mode (pipe-owned per-stream state): the front half first shifts `hop_in` into `ring` and uses the ring
     // as its frame (app3.py:178,226); the back half folds its frame into `ola` and emits `hop_out` (app3.py:219-224)
     const void* hop_in; float* ring; int in_s16; int prime;

@@ -192,6 +192,15 @@ class _Pipe:
         if sch is not None:
             self.lib.check(self.lib.dn_pipe_set_gl_schedule(handle, int(sch)))
 
+        sp = os.environ.get("DN_PIPE_SPLIT")           # likewise: -1 auto, 0 one launch per hop, 1 two (chains, then front halves)
+        if sp is not None:
+            self.set_split(int(sp))
+
+    def set_split(self, mode: int) -> None:
+        """``_lib.DN_SPLIT_AUTO`` / ``DN_SPLIT_OFF`` / ``DN_SPLIT_ON`` (dn_pipe_set_split): a hop as two launches, the chains of the hops in
+        flight and then the new hop's front halves under their own register budget; same samples."""
+        self.lib.check(self.lib.dn_pipe_set_split(self.handle, int(mode)))
+
     def set_gl_schedule(self, schedule: int) -> None:
         """``_lib.DN_GL_AUTO`` / ``DN_GL_WAVE_PER_COLUMN`` / ``DN_GL_WAVE_PER_STREAM`` (dn_pipe_set_gl_schedule): how the pending hop's
         Griffin-Lim is laid out on the GPU; results are bit-identical, call between hops."""

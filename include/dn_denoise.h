@@ -282,6 +282,15 @@ int dn_pipe_set_depth(dn_pipe* p, int32_t depth);
 #define DN_GL_WAVE_PER_COLUMN 1
 #define DN_GL_WAVE_PER_STREAM 2
 int dn_pipe_set_gl_schedule(dn_pipe* p, int32_t schedule);
+/* A hop as TWO launches instead of one: first the Griffin-Lim chains of the hops in flight (what a flush launch is), then the new hop's front
+ * halves (P1-P10) as a launch of their own.  Where a launch carries several times the workgroups the GPU holds at once its chains and its front
+ * halves run as two phases anyway, and a front workgroup compiled into the same kernel as a chain inherits the chain's register budget (two
+ * workgroups per CU); on their own four fit.  Only with the wavefront-per-stream schedule (n_fft 1024) and no head start; same control block,
+ * same samples, still capturable (two kernel nodes).  DN_SPLIT_AUTO (default) decides from the number of chain wavefronts per launch. */
+#define DN_SPLIT_AUTO (-1)
+#define DN_SPLIT_OFF 0
+#define DN_SPLIT_ON 1
+int dn_pipe_set_split(dn_pipe* p, int32_t mode);
 /* Allocates the per-slot buffers for injected initial phases now (otherwise the first submit/push with init_angles does it):
  * call before capturing a parity-mode launch into a hipGraph, where allocation is not allowed. */
 int dn_pipe_reserve_parity(dn_pipe* p);

@@ -502,7 +502,7 @@ def test_mel_stages_at_a_filter_count_that_is_not_a_multiple_of_16(lib):
         lib.dn_dsp_destroy(h)
 
 
-def _run_pipe(lib, dsp, m, schedule, B, n_hops, g, head_start=0, stream=False, s16=False, init=None, n_iter=6, depth=1, flush_after=None):
+def _run_pipe(lib, dsp, m, schedule, B, n_hops, g, head_start=0, stream=False, s16=False, init=None, n_iter=6, depth=1, flush_after=None, split=None):
     """n_hops pipelined hops (frame mode or streaming mode) under one Griffin-Lim schedule; returns everything a hop leaves behind"""
     from audio_denoising_amd._lib import DN_GL_WAVE_PER_STREAM  # noqa: F401
     pipe = C.c_void_p()
@@ -511,6 +511,8 @@ def _run_pipe(lib, dsp, m, schedule, B, n_hops, g, head_start=0, stream=False, s
     lib.check(lib.dn_pipe_set_depth(pipe, depth))
     lib.check(lib.dn_pipe_set_gl_schedule(pipe, schedule))
     lib.check(lib.dn_pipe_set_head_start(pipe, head_start))
+    if split is not None:
+        lib.check(lib.dn_pipe_set_split(pipe, split))
     outs = []
     if not stream:
         hx = np.zeros((B, 17, 5), np.float32)
@@ -546,7 +548,7 @@ def test_griffinlim_one_wavefront_per_stream_is_bit_identical_to_one_per_column(
     """dn_pipe_set_gl_schedule: the wavefront-per-stream Griffin-Lim (four streams a workgroup, the three columns interleaved in one wave,
     overlap-add in registers) must reproduce the three-wave chain bit for bit -- frames, overlap-add lines, emitted hops, hx.  B = 5: a
     full workgroup and one with a single live wave; six iterations (the emulator runs a work-item per OS thread; the gpu tier runs 32)."""
-    from audio_denoising_amd._lib import DN_GL_WAVE_PER_COLUMN, DN_GL_WAVE_PER_STREAM
+    from audio_denoising_amd._lib import DN_GL_WAVE_PER_COLUMN, DN_GL_WAVE_PER_STREAM, DN_SPLIT_OFF, DN_SPLIT_ON
     sig = load_golden("stream_S.npz")["signal"]
     g = {"signal": np.concatenate([sig, 0.5 * sig[:1, ::-1]], axis=0)}          # a fifth stream
     B, n_hops = 5, 2
@@ -556,7 +558,8 @@ def test_griffinlim_one_wavefront_per_stream_is_bit_identical_to_one_per_column(
         rg = np.random.default_rng(7)
         kw["init"] = [emu.f32(rg.random((B, 3, P.n_stft, 2))) for _ in range(n_hops)]
     a = _run_pipe(lib, dsp, m, DN_GL_WAVE_PER_COLUMN, B, n_hops, g, **kw)
-    b = _run_pipe(lib, dsp, m, DN_GL_WAVE_PER_STREAM, B, n_hops, g, **kw)
+    # (the streaming case as a SPLIT hop: the chains' launch, then the front halves' launch with four workgroups a CU and unstaged weights)
+    b = _run_pipe(lib, dsp, m, DN_GL_WAVE_PER_STREAM, B, n_hops, g, split=DN_SPLIT_ON if kw["stream"] else DN_SPLIT_OFF, **kw)
     lib.dn_model_destroy(m)
     assert len(a) == len(b)
     for x, y in zip(a, b):
@@ -571,7 +574,7 @@ def test_deep_pipe_runs_the_chain_in_segments_bit_identically(lib, dsp, depth):
     equal the depth-1 pipe bit for bit -- the emitted hops `depth - 1` pushes later -- also with injected phases and a drain in mid-sequence.
     n_iter = 7 does not divide evenly (segments of 2/2/3, 1/2/2/2 ...); n_iter = 2 < depth leaves empty segments.  (Depth 3, 32 iterations and
     batch 256 run in the gpu tier; the emulator runs a work-item per OS thread.)"""
-    from audio_denoising_amd._lib import DN_GL_WAVE_PER_COLUMN, DN_GL_AUTO
+    from audio_denoising_amd._lib import DN_GL_WAVE_PER_COLUMN, DN_GL_AUTO, DN_SPLIT_ON
     sig = load_golden("stream_S.npz")["signal"]
     g = {"signal": sig}
     B, n_hops = 2, depth + 1
@@ -580,7 +583,7 @@ def test_deep_pipe_runs_the_chain_in_segments_bit_identically(lib, dsp, depth):
     init = [emu.f32(rg.random((B, 3, P.n_stft, 2))) for _ in range(n_hops)]
     for kw in (dict(n_iter=7 if depth == 2 else 3, init=init, flush_after=1),):       # (depth 4 with 3 iterations: an empty segment)
         a = _run_pipe(lib, dsp, m, DN_GL_WAVE_PER_COLUMN, B, n_hops, g, **kw)
-        b = _run_pipe(lib, dsp, m, DN_GL_AUTO, B, n_hops, g, depth=depth, **kw)
+        b = _run_pipe(lib, dsp, m, DN_GL_AUTO, B, n_hops, g, depth=depth, split=DN_SPLIT_ON if depth == 4 else None, **kw)   # (depth 4: as two launches per hop)
         for x, y in zip(a, b):
             assert np.array_equal(x, y)
         assert np.abs(a[0]).max() > 0

@@ -1340,6 +1340,47 @@ def test_app_parameters_refuse_the_schedules_built_for_n_fft_1024(dev):
     pipe.set_depth(1)
 
 
+@pytest.mark.parametrize("batch,depth,stream", [(1027, 1, False), (300, 2, True), (4100, 1, True)])
+def test_split_hop_is_bit_identical_to_the_single_launch(dev, batch, depth, stream):
+    """dn_pipe_set_split: a hop as two launches (the chains of the hops in flight, then the new hop's front halves as a launch of their own:
+    four workgroups a CU, weights read from L2) against the one-launch hop -- frames / emitted hops, hx and stream state bit for bit; 4,100
+    streams is above the automatic threshold (DN_SPLIT_AUTO), so there the default is compared with DN_SPLIT_OFF."""
+    from audio_denoising_amd import _lib
+    from audio_denoising_amd.pipeline import Denoiser, HopPipeline, PipelinedStream
+    p = _params("S")
+    dn = Denoiser(_model(dev, 5), p.sample_rate, p.n_fft, p.hop, p.n_mels)
+    g = torch.Generator().manual_seed(batch)
+    n = 5
+    res = []
+    for mode in (_lib.DN_SPLIT_OFF, _lib.DN_SPLIT_AUTO if batch >= 4096 else _lib.DN_SPLIT_ON):
+        if stream:
+            g.manual_seed(batch)
+            sig = (0.3 * torch.randn(batch, n * p.hop, generator=g)).clamp(-1, 1).to(dev)
+            ps = PipelinedStream(dn, batch, seed=5)
+            ps.set_depth(depth)
+            ps.set_gl_schedule(_lib.DN_GL_WAVE_PER_STREAM if depth == 1 else _lib.DN_GL_AUTO)
+            ps.set_split(mode)
+            outs = [ps.push(sig[:, i * p.hop:(i + 1) * p.hop].contiguous()) for i in range(n)] + [ps.flush()]
+            res.append([torch.cat(outs, 1)] + list(ps.state()[:3]))
+        else:
+            g.manual_seed(batch)
+            frames = [(0.1 * torch.randn(batch, p.n_fft, generator=g)).to(dev) for _ in range(n)]
+            pipe = HopPipeline(dn, batch)
+            pipe.set_depth(depth)
+            pipe.set_gl_schedule(_lib.DN_GL_WAVE_PER_STREAM)
+            pipe.set_split(mode)
+            hx = dn.init_hx(batch)
+            outs = [torch.empty(batch, p.n_fft, device=dev) for _ in range(n)]
+            for i in range(n):
+                pipe.submit(frames[i], hx, outs[i], seed=9)
+            pipe.flush()
+            torch.cuda.synchronize()
+            res.append(outs + [hx])
+    for x, y in zip(*res):
+        assert torch.equal(x, y)
+    assert res[0][0].abs().max().item() > 1e-3
+
+
 def test_several_pushes_captured_as_one_graph_replay(dev):
     """`PipelinedStream.graph_step` with (K, B, hop) tensors: K consecutive pushes captured as ONE hipGraph (one graph launch per K hops).  Four
     replays of a three-push graph equal twelve eager pushes bit for bit."""
