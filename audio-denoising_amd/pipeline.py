@@ -426,6 +426,109 @@ class HostFedStream(PipelinedStream):
         return torch.cat(parts + [tail], dim=1)
 
 
+class _Queues:
+    """B independent streams as Q pipes of B/Q streams, each on a HIP stream (hardware queue) of its own, every hop split in two launches
+    (``dn_pipe_set_split``: the chains of the hops in flight, then the new hop's front halves as a kernel of their own).  Streams do not
+    depend on one another, so neither do the pipes: no event ever crosses from one queue to another, and while one pipe's chains (243
+    registers a wavefront) occupy a SIMD the other pipe's front halves (101-112 registers) run beside them -- three wavefronts per SIMD where
+    one launch allows two.  Measured on one MI355X: 1,024 streams 153.9 -> 138.9 us per hop (two queues, depth 2), 2,048 streams
+    292 -> 262 us (two queues, depth 1); below 1,024 streams a single pipe is faster.  Same samples as one pipe of B streams bit for bit
+    (the generator is keyed by the global stream id).
+    The queues are this object's own: ``after(stream)`` makes them wait for work already enqueued on ``stream`` (inputs produced there),
+    ``before(stream)`` makes ``stream`` wait for everything enqueued on them so far (outputs consumed there), ``synchronize()`` blocks the
+    host.  Without those calls the caller's tensors must simply be ready before ``submit`` / ``push_`` and untouched until
+    ``synchronize`` -- the usual contract of a stream."""
+
+    def _setup(self, denoiser: "Denoiser", batch: int, queues: int, depth: int, split: bool, make):
+        if queues < 1 or batch < queues:
+            raise ValueError("queues must be between 1 and the number of streams")
+        self.dn, self.batch, self.depth = denoiser, batch, depth
+        self.bounds = [(batch * q) // queues for q in range(queues + 1)]          # contiguous blocks of streams, sizes differing by at most one
+        with torch.cuda.device(denoiser.device):
+            self.streams = [torch.cuda.Stream(device=denoiser.device) for _ in range(queues)]
+        self.pipes = []
+        for q in range(queues):
+            pipe = make(self.bounds[q + 1] - self.bounds[q], self.bounds[q])
+            if depth != 1:
+                pipe.set_depth(depth)
+            elif denoiser.n_fft == 1024:
+                pipe.set_gl_schedule(_lib.DN_GL_WAVE_PER_STREAM)                 # (what a split hop needs)
+            pipe.set_split(_lib.DN_SPLIT_ON if split and denoiser.n_fft == 1024 else _lib.DN_SPLIT_OFF)
+            self.pipes.append(pipe)
+
+    def _each(self):
+        for q, pipe in enumerate(self.pipes):
+            yield pipe, self.streams[q], self.bounds[q], self.bounds[q + 1]
+
+    def after(self, stream: "torch.cuda.Stream | None" = None) -> None:
+        ev = (stream or torch.cuda.current_stream(self.dn.device)).record_event()
+        for st in self.streams:
+            st.wait_event(ev)
+
+    def before(self, stream: "torch.cuda.Stream | None" = None) -> None:
+        tgt = stream or torch.cuda.current_stream(self.dn.device)
+        for st in self.streams:
+            tgt.wait_event(st.record_event())
+
+    def synchronize(self) -> None:
+        for st in self.streams:
+            st.synchronize()
+
+
+class QueuedHopPipelines(_Queues):
+    """``HopPipeline`` for B streams as ``queues`` pipes on as many HIP streams (see ``_Queues``).  ``submit`` / ``flush`` as ``HopPipeline``;
+    row block q of ``frames`` / ``hx`` / ``out`` belongs to pipe q."""
+
+    def __init__(self, denoiser: "Denoiser", batch: int, queues: int = 2, depth: int = 2, split: bool = True):
+        self._setup(denoiser, batch, queues, depth, split, lambda n, lo: HopPipeline(denoiser, n))
+
+    def submit(self, frames: torch.Tensor, hx: torch.Tensor, out: torch.Tensor, seed: int = 0, stream_id0: int = 0,
+               init_angles: torch.Tensor | None = None, check_weights: bool = True) -> None:
+        for pipe, st, lo, hi in self._each():
+            with torch.cuda.stream(st):
+                pipe.submit(frames[lo:hi], hx[lo:hi], out[lo:hi], seed=seed, stream_id0=stream_id0 + lo,
+                            init_angles=None if init_angles is None else init_angles[lo:hi], check_weights=check_weights)
+
+    def flush(self) -> None:
+        for pipe, st, lo, hi in self._each():
+            with torch.cuda.stream(st):
+                pipe.flush()
+
+
+class QueuedPipelinedStreams(_Queues):
+    """``PipelinedStream`` for B streams as ``queues`` pipes on as many HIP streams (see ``_Queues``): ``push_`` / ``flush`` / ``graph_steps``."""
+
+    def __init__(self, denoiser: "Denoiser", batch: int, queues: int = 2, depth: int = 2, split: bool = True, stream_id0: int = 0, seed: int = 0):
+        self._setup(denoiser, batch, queues, depth, split, lambda n, lo: PipelinedStream(denoiser, n, stream_id0=stream_id0 + lo, seed=seed))
+
+    def push_(self, hop: torch.Tensor, out: torch.Tensor, check_weights: bool = True) -> None:
+        for pipe, st, lo, hi in self._each():
+            with torch.cuda.stream(st):
+                pipe.push_(hop[lo:hi], out[lo:hi], check_weights=check_weights)
+
+    def flush(self, s16: bool = False) -> torch.Tensor:
+        parts = []
+        for pipe, st, lo, hi in self._each():
+            with torch.cuda.stream(st):
+                parts.append(pipe.flush(s16=s16))
+        self.synchronize()
+        return torch.cat(parts, dim=0)
+
+    def graph_steps(self, hop: torch.Tensor, out: torch.Tensor):
+        """One captured graph per queue (``PipelinedStream.graph_step`` of its row block of the (B, hop_length) tensors); returns ``replay()``,
+        which launches each graph on its queue."""
+        graphs = []
+        for pipe, st, lo, hi in self._each():
+            with torch.cuda.stream(st):
+                graphs.append((pipe.graph_step(hop[lo:hi], out[lo:hi]), st))
+
+        def replay():
+            for g, st in graphs:
+                with torch.cuda.stream(st):
+                    g.replay()
+        return replay
+
+
 class DenoiserStream:
     """B concurrent streams with persistent device state: input ring, output overlap-add buffer, hx.
 

@@ -153,6 +153,30 @@ def time_pipe(dn, B, dev, steps, depth=1, seconds=None):
     return B * steps / el, 1e3 * el / steps
 
 
+def time_queued(dn, B, dev, steps, queues=2, depth=2):
+    """frames/s of B streams as `queues` pipes on as many HIP streams, split hops (pipeline.QueuedHopPipelines): steady state + flush."""
+    from audio_denoising_amd.pipeline import QueuedHopPipelines
+    g = torch.Generator().manual_seed(4321)
+    frames = (0.1 * torch.randn(B, dn.n_fft, generator=g)).to(dev)
+    hx = dn.init_hx(B)
+    out = torch.empty_like(frames)
+    torch.cuda.synchronize()
+    qp = QueuedHopPipelines(dn, B, queues=queues, depth=depth)
+
+    def step():
+        qp.submit(frames, hx, out, seed=1, check_weights=False)
+    prewarm(step, 0.3)
+    qp.flush()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    qp.flush()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    return B * steps / el, 1e3 * el / steps
+
+
 def extra_measurements(args, dev, budget_steps=1500):
     """Bounded side numbers carried in the same JSON line (about a second each): BASELINE config 3 (bf16 MFMA conv tiles), config 5's per-GPU
     share (1,024 streams, ONE hipGraph-captured push replayed per hop), the reference app's own parameters (n_fft 1536), the saturated regime,
@@ -200,11 +224,28 @@ def extra_measurements(args, dev, budget_steps=1500):
     ps.flush()
     res["config5_stream_graph_1024"]["graph_of_8_hops"] = {"value": round(B5 * (n5 // K8) * K8 / el, 1), "unit": "frames/s",
                                                            "ms_per_step": round(1e3 * el / ((n5 // K8) * K8), 4)}
+    # ... and as two independent streaming pipes of 512 on two HIP streams (depth 2, split hops), one captured push per pipe and hop
+    from audio_denoising_amd.pipeline import QueuedPipelinedStreams
+    torch.cuda.synchronize()
+    qs = QueuedPipelinedStreams(dn, B5, queues=2, depth=2)
+    replay = qs.graph_steps(hop, hop_out)
+    prewarm(replay)
+    t0 = time.perf_counter()
+    for _ in range(n5):
+        replay()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    qs.flush()
+    res["config5_stream_graph_1024"]["two_queues_depth2"] = {"value": round(B5 * n5 / el, 1), "unit": "frames/s", "ms_per_step": round(1e3 * el / n5, 4)}
     # saturated regime (wavefront-per-stream Griffin-Lim)
     for b, n in ((1024, 300), (8192, 40)):
         v, ms = time_pipe(dn, b, dev, n, 1)
         res[f"batch_{b}"] = {"value": round(v, 1), "unit": "frames/s", "ms_per_step": round(ms, 4),
                              "fp32_frac": round(TOTAL_FLOP_PER_FRAME * v / 1e12 / PEAK_FP32_TFLOPS, 4)}
+    # 1,024 streams as two independent pipes of 512 on two HIP streams, depth 2, split hops: one pipe's chains beside the other's front halves
+    v, ms = time_queued(dn, 1024, dev, 300, queues=2, depth=2)
+    res["batch_1024"]["two_queues_depth2"] = {"value": round(v, 1), "unit": "frames/s", "ms_per_step": round(ms, 4),
+                                              "fp32_frac": round(TOTAL_FLOP_PER_FRAME * v / 1e12 / PEAK_FP32_TFLOPS, 4)}
     # the reference app's own STFT parameters (app3.py:29-33): 48 kHz, n_fft 1536, 64 mels
     dnr = build_denoiser(dev, "R1", "fp32")
     v, ms = time_pipe(dnr, BATCH, dev, 600, 1)
@@ -360,6 +401,16 @@ def side_measurement(args, dn, B, dev):
             dframes[s].copy_(host_in, non_blocking=True)
             pipe.submit(dframes[s], hx, douts[s], seed=1000)              # also completes hop i-1 (its Griffin-Lim blocks)
             host_out[s ^ 1].copy_(douts[s ^ 1], non_blocking=True)
+        fin = pipe.flush
+    elif args.queues > 1:
+        from audio_denoising_amd.pipeline import QueuedHopPipelines
+        frames = (0.1 * torch.randn(B, dn.n_fft, generator=g)).to(dev)
+        torch.cuda.synchronize()
+        pipe = QueuedHopPipelines(dn, B, queues=args.queues, depth=args.depth if args.depth > 0 else 2)
+        mode = f"frames, {args.queues} pipes on {args.queues} HIP streams, split hops, depth {pipe.depth}"
+
+        def step(i):
+            pipe.submit(frames, hx, out, seed=1000, check_weights=False)
         fin = pipe.flush
     else:
         frames = (0.1 * torch.randn(B, dn.n_fft, generator=g)).to(dev)
@@ -522,6 +573,7 @@ def main():
     ap.add_argument("--pcie", action="store_true", help="side measurement: frames arrive in pinned host memory and results return to it every hop")
     ap.add_argument("--stream", action="store_true", help="streaming mode (BASELINE config 5): pipe-owned ring/overlap-add/hx state, one hop of new samples per step")
     ap.add_argument("--graph", action="store_true", help="with --stream: replay ONE hipGraph-captured push per step")
+    ap.add_argument("--queues", type=int, default=1, help="side measurement: the batch as this many independent pipes on as many HIP streams")
     ap.add_argument("--graph-hops", type=int, default=1, help="with --stream --graph: consecutive pushes captured per graph")
     ap.add_argument("--depth", type=int, default=0, help="hops of one stream in flight (dn_pipe_set_depth, 1..4); 0 = the throughput default for the batch "
                                                             "(4 up to 384 streams, 2 below 768, else 1); 1 = output after the next hop")

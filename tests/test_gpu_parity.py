@@ -1381,6 +1381,64 @@ def test_split_hop_is_bit_identical_to_the_single_launch(dev, batch, depth, stre
     assert res[0][0].abs().max().item() > 1e-3
 
 
+@pytest.mark.parametrize("batch,queues,depth", [(1024, 2, 2), (37, 3, 1)])
+def test_queued_pipes_equal_one_pipe(dev, batch, queues, depth):
+    """`QueuedHopPipelines` / `QueuedPipelinedStreams`: B streams as Q pipes on Q HIP streams, split hops (the 1,024-stream configuration: two
+    queues at depth 2).  Frames, hx, emitted hops and captured replays must equal ONE pipe of B streams bit for bit -- the generator is keyed by
+    the global stream id, so sharding streams over queues changes nothing."""
+    from audio_denoising_amd.pipeline import Denoiser, HopPipeline, PipelinedStream, QueuedHopPipelines, QueuedPipelinedStreams
+    p = _params("S")
+    dn = Denoiser(_model(dev, 5), p.sample_rate, p.n_fft, p.hop, p.n_mels)
+    g = torch.Generator().manual_seed(batch)
+    n = 4
+    frames = [(0.1 * torch.randn(batch, p.n_fft, generator=g)).to(dev) for _ in range(n)]
+    sig = (0.3 * torch.randn(batch, n * p.hop, generator=g)).clamp(-1, 1).to(dev)
+    torch.cuda.synchronize()
+    # frame mode
+    one = HopPipeline(dn, batch)
+    one.set_depth(depth)
+    hx1 = dn.init_hx(batch)
+    o1 = [torch.empty(batch, p.n_fft, device=dev) for _ in range(n)]
+    for i in range(n):
+        one.submit(frames[i], hx1, o1[i], seed=9, stream_id0=5)
+    one.flush()
+    qp = QueuedHopPipelines(dn, batch, queues=queues, depth=depth)
+    hx2 = dn.init_hx(batch)
+    o2 = [torch.empty(batch, p.n_fft, device=dev) for _ in range(n)]
+    qp.after()
+    for i in range(n):
+        qp.submit(frames[i], hx2, o2[i], seed=9, stream_id0=5)
+    qp.flush()
+    qp.synchronize()
+    torch.cuda.synchronize()
+    for x, y in zip(o1 + [hx1], o2 + [hx2]):
+        assert torch.equal(x, y)
+    assert o1[0].abs().max().item() > 1e-3
+    # streaming mode, eager and captured
+    ps = PipelinedStream(dn, batch, seed=3, stream_id0=7)
+    ps.set_depth(depth)
+    a = torch.cat([ps.push(sig[:, i * p.hop:(i + 1) * p.hop].contiguous()) for i in range(n)] + [ps.flush()], 1)
+    for captured in (False, True):
+        qs = QueuedPipelinedStreams(dn, batch, queues=queues, depth=depth, seed=3, stream_id0=7)
+        hop = torch.empty(batch, p.hop, device=dev)
+        out = torch.empty(batch, p.hop, device=dev)
+        replay = qs.graph_steps(hop, out) if captured else None
+        res = []
+        for i in range(n):
+            hop.copy_(sig[:, i * p.hop:(i + 1) * p.hop])
+            qs.after()
+            if captured:
+                replay()
+            else:
+                qs.push_(hop, out)
+            qs.before()
+            res.append(out.clone())
+        qs.before()
+        torch.cuda.synchronize()
+        b = torch.cat(res + [qs.flush()[:, :depth * p.hop]], 1)
+        assert torch.equal(a, b), "captured" if captured else "eager"
+
+
 def test_several_pushes_captured_as_one_graph_replay(dev):
     """`PipelinedStream.graph_step` with (K, B, hop) tensors: K consecutive pushes captured as ONE hipGraph (one graph launch per K hops).  Four
     replays of a three-push graph equal twelve eager pushes bit for bit."""

@@ -13,6 +13,9 @@ run --stream --graph --graph-hops 8 --batch 1024 --steps 400      # ... eight pu
 run --batch 512
 run --batch 768
 run --batch 1024
+run --batch 1024 --queues 2 --depth 2           # two independent pipes of 512 on two HIP streams, split hops
+run --batch 2048
+run --batch 2048 --queues 2 --depth 1
 run --batch 4096
 run --batch 8192
 run --stream --batch 256 --depth 4
