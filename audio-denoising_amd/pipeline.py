@@ -529,6 +529,40 @@ class QueuedPipelinedStreams(_Queues):
         return replay
 
 
+def throughput_plan(batch: int, n_fft: int = 1024) -> dict:
+    """How to run ``batch`` independent streams on one MI355X for throughput, by the measurements in DESIGN.md (sections 4.6-4.9;
+    ``profiles/r03_v6_*``): ``{"queues", "depth", "split"}`` for ``hop_pipeline`` / ``QueuedHopPipelines``.  Every choice gives the same
+    samples; what changes is the number of hops between a submit and its output (``depth``).
+      up to 384 streams    one pipe, four hops in flight (batch 256: 45.8 us per hop against 56.0 at depth 1)
+      385 .. 1,023         one pipe, two hops in flight
+      1,024 .. 2,047       two pipes on two HIP streams, split hops, two hops in flight (1,024 streams: 7.6 M frames/s against 6.7 M)
+      2,048 .. 4,095       two pipes on two HIP streams, split hops, one hop in flight (2,048 streams: 8.0 M against 7.0 M)
+      4,096 and up         one pipe, one hop in flight, split hops (DN_SPLIT_AUTO)
+    n_fft 1536 (the wavefront-per-stream schedule is not built there): one pipe at depth 1."""
+    if n_fft != 1024:
+        return {"queues": 1, "depth": 1, "split": False}
+    if batch <= 384:
+        return {"queues": 1, "depth": 4, "split": False}
+    if batch < 1024:
+        return {"queues": 1, "depth": 2, "split": False}
+    if batch < 2048:
+        return {"queues": 2, "depth": 2, "split": True}
+    if batch < 4096:
+        return {"queues": 2, "depth": 1, "split": True}
+    return {"queues": 1, "depth": 1, "split": True}
+
+
+def hop_pipeline(denoiser: "Denoiser", batch: int):
+    """The frame-mode pipe ``throughput_plan`` picks for ``batch`` streams: a ``HopPipeline`` or ``QueuedHopPipelines`` (same ``submit`` /
+    ``flush``; the queued form also wants ``after()`` / ``before()`` or ``synchronize()`` around the caller's own stream)."""
+    plan = throughput_plan(batch, denoiser.n_fft)
+    if plan["queues"] > 1:
+        return QueuedHopPipelines(denoiser, batch, queues=plan["queues"], depth=plan["depth"], split=plan["split"])
+    pipe = HopPipeline(denoiser, batch)
+    pipe.set_depth(plan["depth"])
+    return pipe
+
+
 class DenoiserStream:
     """B concurrent streams with persistent device state: input ring, output overlap-add buffer, hx.
 

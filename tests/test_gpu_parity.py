@@ -1439,6 +1439,25 @@ def test_queued_pipes_equal_one_pipe(dev, batch, queues, depth):
         assert torch.equal(a, b), "captured" if captured else "eager"
 
 
+def test_hop_pipeline_picks_the_planned_composition(dev):
+    """`pipeline.hop_pipeline`: the composition `throughput_plan` names is what gets built (1,024 streams: two pipes at depth 2 on two HIP
+    streams; 300: one pipe at depth 4), and it runs."""
+    from audio_denoising_amd.pipeline import Denoiser, HopPipeline, QueuedHopPipelines, hop_pipeline
+    p = _params("S")
+    dn = Denoiser(_model(dev, 5), p.sample_rate, p.n_fft, p.hop, p.n_mels, n_iter=4)
+    a, b = hop_pipeline(dn, 1024), hop_pipeline(dn, 300)
+    assert isinstance(a, QueuedHopPipelines) and len(a.pipes) == 2 and a.depth == 2 and [q.batch for q in a.pipes] == [512, 512]
+    assert isinstance(b, HopPipeline) and b.depth == 4
+    frames = 0.1 * torch.randn(1024, p.n_fft, device=dev)
+    hx, out = dn.init_hx(1024), torch.zeros(1024, p.n_fft, device=dev)
+    torch.cuda.synchronize()
+    for _ in range(3):
+        a.submit(frames, hx, out, seed=1)
+    a.flush()
+    a.synchronize()
+    assert torch.isfinite(out).all() and out.abs().max().item() > 1e-3 and out[700:].abs().max().item() > 1e-3
+
+
 def test_several_pushes_captured_as_one_graph_replay(dev):
     """`PipelinedStream.graph_step` with (K, B, hop) tensors: K consecutive pushes captured as ONE hipGraph (one graph launch per K hops).  Four
     replays of a three-push graph equal twelve eager pushes bit for bit."""

@@ -131,3 +131,15 @@ def test_product_package_never_imports_the_oracle():
                 src = open(os.path.join(root, fn)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), fn
                 assert "tests/emu" not in src and "dn_emu" not in src, fn
+
+
+def test_throughput_plan_follows_the_measured_thresholds():
+    """pipeline.throughput_plan: pure host logic (DESIGN.md sections 4.6-4.9) -- which composition of pipes, depth and split a batch gets."""
+    from audio_denoising_amd.pipeline import throughput_plan
+    assert throughput_plan(256) == {"queues": 1, "depth": 4, "split": False}          # the metric's configuration
+    assert throughput_plan(384)["depth"] == 4 and throughput_plan(385)["depth"] == 2
+    assert throughput_plan(1023) == {"queues": 1, "depth": 2, "split": False}
+    assert throughput_plan(1024) == {"queues": 2, "depth": 2, "split": True}           # configs 4 / 5: 1,024 streams per GPU
+    assert throughput_plan(2048) == {"queues": 2, "depth": 1, "split": True}
+    assert throughput_plan(4096) == {"queues": 1, "depth": 1, "split": True} == throughput_plan(8192)
+    assert throughput_plan(1024, n_fft=1536) == {"queues": 1, "depth": 1, "split": False}
