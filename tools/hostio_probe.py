@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Where does a host-fed push spend its time?  (tools only)"""
+"""Where does a host-fed push spend its time?  (tools only)
+    python tools/hostio_probe.py [batch] [depth] [staged|zc] [none|memmove|nt]
+(feed "nt": gcc -O2 -shared -fPIC -o tools/build/nt_copy.so tools/nt_copy.c first)"""
 import ctypes as C
 import os
 import sys
