@@ -439,15 +439,16 @@ class _Queues:
     host.  Without those calls the caller's tensors must simply be ready before ``submit`` / ``push_`` and untouched until
     ``synchronize`` -- the usual contract of a stream."""
 
-    def _setup(self, denoiser: "Denoiser", batch: int, queues: int, depth: int, split: bool, make):
-        if queues < 1 or batch < queues:
-            raise ValueError("queues must be between 1 and the number of streams")
+    def _setup(self, denoiser: "Denoiser", batch: int, queues: int, depth: int, split: bool, make, pipes: int | None = None):
+        n_pipes = queues if pipes is None else pipes          # more pipes than queues: pipe i runs on queue i % queues, one after the other
+        if queues < 1 or n_pipes < queues or batch < n_pipes:
+            raise ValueError("1 <= queues <= pipes <= number of streams")
         self.dn, self.batch, self.depth = denoiser, batch, depth
-        self.bounds = [(batch * q) // queues for q in range(queues + 1)]          # contiguous blocks of streams, sizes differing by at most one
+        self.bounds = [(batch * q) // n_pipes for q in range(n_pipes + 1)]        # contiguous blocks of streams, sizes differing by at most one
         with torch.cuda.device(denoiser.device):
             self.streams = [torch.cuda.Stream(device=denoiser.device) for _ in range(queues)]
         self.pipes = []
-        for q in range(queues):
+        for q in range(n_pipes):
             pipe = make(self.bounds[q + 1] - self.bounds[q], self.bounds[q])
             if depth != 1:
                 pipe.set_depth(depth)
@@ -458,7 +459,7 @@ class _Queues:
 
     def _each(self):
         for q, pipe in enumerate(self.pipes):
-            yield pipe, self.streams[q], self.bounds[q], self.bounds[q + 1]
+            yield pipe, self.streams[q % len(self.streams)], self.bounds[q], self.bounds[q + 1]
 
     def after(self, stream: "torch.cuda.Stream | None" = None) -> None:
         ev = (stream or torch.cuda.current_stream(self.dn.device)).record_event()
@@ -479,8 +480,8 @@ class QueuedHopPipelines(_Queues):
     """``HopPipeline`` for B streams as ``queues`` pipes on as many HIP streams (see ``_Queues``).  ``submit`` / ``flush`` as ``HopPipeline``;
     row block q of ``frames`` / ``hx`` / ``out`` belongs to pipe q."""
 
-    def __init__(self, denoiser: "Denoiser", batch: int, queues: int = 2, depth: int = 2, split: bool = True):
-        self._setup(denoiser, batch, queues, depth, split, lambda n, lo: HopPipeline(denoiser, n))
+    def __init__(self, denoiser: "Denoiser", batch: int, queues: int = 2, depth: int = 2, split: bool = True, pipes: int | None = None):
+        self._setup(denoiser, batch, queues, depth, split, lambda n, lo: HopPipeline(denoiser, n), pipes)
 
     def submit(self, frames: torch.Tensor, hx: torch.Tensor, out: torch.Tensor, seed: int = 0, stream_id0: int = 0,
                init_angles: torch.Tensor | None = None, check_weights: bool = True) -> None:
@@ -498,8 +499,9 @@ class QueuedHopPipelines(_Queues):
 class QueuedPipelinedStreams(_Queues):
     """``PipelinedStream`` for B streams as ``queues`` pipes on as many HIP streams (see ``_Queues``): ``push_`` / ``flush`` / ``graph_steps``."""
 
-    def __init__(self, denoiser: "Denoiser", batch: int, queues: int = 2, depth: int = 2, split: bool = True, stream_id0: int = 0, seed: int = 0):
-        self._setup(denoiser, batch, queues, depth, split, lambda n, lo: PipelinedStream(denoiser, n, stream_id0=stream_id0 + lo, seed=seed))
+    def __init__(self, denoiser: "Denoiser", batch: int, queues: int = 2, depth: int = 2, split: bool = True, stream_id0: int = 0, seed: int = 0,
+                 pipes: int | None = None):
+        self._setup(denoiser, batch, queues, depth, split, lambda n, lo: PipelinedStream(denoiser, n, stream_id0=stream_id0 + lo, seed=seed), pipes)
 
     def push_(self, hop: torch.Tensor, out: torch.Tensor, check_weights: bool = True) -> None:
         for pipe, st, lo, hi in self._each():
@@ -531,25 +533,23 @@ class QueuedPipelinedStreams(_Queues):
 
 def throughput_plan(batch: int, n_fft: int = 1024) -> dict:
     """How to run ``batch`` independent streams on one MI355X for throughput, by the measurements in DESIGN.md (sections 4.6-4.9;
-    ``profiles/r03_v6_*``): ``{"queues", "depth", "split"}`` for ``hop_pipeline`` / ``QueuedHopPipelines``.  Every choice gives the same
-    samples; what changes is the number of hops between a submit and its output (``depth``).
+    ``profiles/r03_v6_*``): ``{"queues", "pipes", "depth", "split"}`` for ``hop_pipeline`` / ``QueuedHopPipelines``.  Every choice gives the
+    same samples; what changes is the number of hops between a submit and its output (``depth``).
       up to 384 streams    one pipe, four hops in flight (batch 256: 45.8 us per hop against 56.0 at depth 1)
       385 .. 1,023         one pipe, two hops in flight
       1,024 .. 2,047       two pipes on two HIP streams, split hops, two hops in flight (1,024 streams: 7.6 M frames/s against 6.7 M)
-      2,048 .. 4,095       two pipes on two HIP streams, split hops, one hop in flight (2,048 streams: 8.0 M against 7.0 M)
-      4,096 and up         one pipe, one hop in flight, split hops (DN_SPLIT_AUTO)
+      2,048 and up         an even number of pipes of about 1,024 streams, taking turns on two HIP streams, split hops, one hop in flight
+                           (2,048 / 4,096 / 8,192 streams: 8.0 M frames/s against 7.0 / 7.3 / 7.6 M for one pipe)
     n_fft 1536 (the wavefront-per-stream schedule is not built there): one pipe at depth 1."""
     if n_fft != 1024:
-        return {"queues": 1, "depth": 1, "split": False}
+        return {"queues": 1, "pipes": 1, "depth": 1, "split": False}
     if batch <= 384:
-        return {"queues": 1, "depth": 4, "split": False}
+        return {"queues": 1, "pipes": 1, "depth": 4, "split": False}
     if batch < 1024:
-        return {"queues": 1, "depth": 2, "split": False}
+        return {"queues": 1, "pipes": 1, "depth": 2, "split": False}
     if batch < 2048:
-        return {"queues": 2, "depth": 2, "split": True}
-    if batch < 4096:
-        return {"queues": 2, "depth": 1, "split": True}
-    return {"queues": 1, "depth": 1, "split": True}
+        return {"queues": 2, "pipes": 2, "depth": 2, "split": True}
+    return {"queues": 2, "pipes": 2 * (batch // 2048), "depth": 1, "split": True}
 
 
 def hop_pipeline(denoiser: "Denoiser", batch: int):
@@ -557,7 +557,7 @@ def hop_pipeline(denoiser: "Denoiser", batch: int):
     ``flush``; the queued form also wants ``after()`` / ``before()`` or ``synchronize()`` around the caller's own stream)."""
     plan = throughput_plan(batch, denoiser.n_fft)
     if plan["queues"] > 1:
-        return QueuedHopPipelines(denoiser, batch, queues=plan["queues"], depth=plan["depth"], split=plan["split"])
+        return QueuedHopPipelines(denoiser, batch, queues=plan["queues"], depth=plan["depth"], split=plan["split"], pipes=plan["pipes"])
     pipe = HopPipeline(denoiser, batch)
     pipe.set_depth(plan["depth"])
     return pipe

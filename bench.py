@@ -153,7 +153,7 @@ def time_pipe(dn, B, dev, steps, depth=1, seconds=None):
     return B * steps / el, 1e3 * el / steps
 
 
-def time_queued(dn, B, dev, steps, queues=2, depth=2):
+def time_queued(dn, B, dev, steps, queues=2, depth=2, pipes=None):
     """frames/s of B streams as `queues` pipes on as many HIP streams, split hops (pipeline.QueuedHopPipelines): steady state + flush."""
     from audio_denoising_amd.pipeline import QueuedHopPipelines
     g = torch.Generator().manual_seed(4321)
@@ -161,11 +161,11 @@ def time_queued(dn, B, dev, steps, queues=2, depth=2):
     hx = dn.init_hx(B)
     out = torch.empty_like(frames)
     torch.cuda.synchronize()
-    qp = QueuedHopPipelines(dn, B, queues=queues, depth=depth)
+    qp = QueuedHopPipelines(dn, B, queues=queues, depth=depth, pipes=pipes)
 
     def step():
         qp.submit(frames, hx, out, seed=1, check_weights=False)
-    prewarm(step, 0.3)
+    prewarm(step, 0.3 if B <= 1024 else 0.1)
     qp.flush()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -242,10 +242,14 @@ def extra_measurements(args, dev, budget_steps=1500):
         v, ms = time_pipe(dn, b, dev, n, 1)
         res[f"batch_{b}"] = {"value": round(v, 1), "unit": "frames/s", "ms_per_step": round(ms, 4),
                              "fp32_frac": round(TOTAL_FLOP_PER_FRAME * v / 1e12 / PEAK_FP32_TFLOPS, 4)}
-    # 1,024 streams as two independent pipes of 512 on two HIP streams, depth 2, split hops: one pipe's chains beside the other's front halves
-    v, ms = time_queued(dn, 1024, dev, 300, queues=2, depth=2)
-    res["batch_1024"]["two_queues_depth2"] = {"value": round(v, 1), "unit": "frames/s", "ms_per_step": round(ms, 4),
-                                              "fp32_frac": round(TOTAL_FLOP_PER_FRAME * v / 1e12 / PEAK_FP32_TFLOPS, 4)}
+    # the same streams as independent split-hop pipes taking turns on two HIP streams (pipeline.throughput_plan: 1,024 streams as two pipes of 512
+    # at depth 2, 8,192 as eight pipes of 1,024 at depth 1): one pipe's chains run beside another's front halves
+    from audio_denoising_amd.pipeline import throughput_plan
+    for b, n in ((1024, 300), (8192, 40)):
+        plan = throughput_plan(b, N_FFT)
+        v, ms = time_queued(dn, b, dev, n, queues=plan["queues"], depth=plan["depth"], pipes=plan["pipes"])
+        res[f"batch_{b}"]["queued"] = {"value": round(v, 1), "unit": "frames/s", "ms_per_step": round(ms, 4), "plan": plan,
+                                       "fp32_frac": round(TOTAL_FLOP_PER_FRAME * v / 1e12 / PEAK_FP32_TFLOPS, 4)}
     # the reference app's own STFT parameters (app3.py:29-33): 48 kHz, n_fft 1536, 64 mels
     dnr = build_denoiser(dev, "R1", "fp32")
     v, ms = time_pipe(dnr, BATCH, dev, 600, 1)
@@ -406,8 +410,8 @@ def side_measurement(args, dn, B, dev):
         from audio_denoising_amd.pipeline import QueuedHopPipelines
         frames = (0.1 * torch.randn(B, dn.n_fft, generator=g)).to(dev)
         torch.cuda.synchronize()
-        pipe = QueuedHopPipelines(dn, B, queues=args.queues, depth=args.depth if args.depth > 0 else 2)
-        mode = f"frames, {args.queues} pipes on {args.queues} HIP streams, split hops, depth {pipe.depth}"
+        pipe = QueuedHopPipelines(dn, B, queues=args.queues, depth=args.depth if args.depth > 0 else 2, pipes=args.pipes if args.pipes > 0 else None)
+        mode = f"frames, {len(pipe.pipes)} pipes on {args.queues} HIP streams, split hops, depth {pipe.depth}"
 
         def step(i):
             pipe.submit(frames, hx, out, seed=1000, check_weights=False)
@@ -574,6 +578,7 @@ def main():
     ap.add_argument("--stream", action="store_true", help="streaming mode (BASELINE config 5): pipe-owned ring/overlap-add/hx state, one hop of new samples per step")
     ap.add_argument("--graph", action="store_true", help="with --stream: replay ONE hipGraph-captured push per step")
     ap.add_argument("--queues", type=int, default=1, help="side measurement: the batch as this many independent pipes on as many HIP streams")
+    ap.add_argument("--pipes", type=int, default=0, help="with --queues: the batch as this many pipes (default: one per queue), pipe i on queue i %% queues")
     ap.add_argument("--graph-hops", type=int, default=1, help="with --stream --graph: consecutive pushes captured per graph")
     ap.add_argument("--depth", type=int, default=0, help="hops of one stream in flight (dn_pipe_set_depth, 1..4); 0 = the throughput default for the batch "
                                                             "(4 up to 384 streams, 2 below 768, else 1); 1 = output after the next hop")

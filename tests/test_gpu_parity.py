@@ -1381,10 +1381,10 @@ def test_split_hop_is_bit_identical_to_the_single_launch(dev, batch, depth, stre
     assert res[0][0].abs().max().item() > 1e-3
 
 
-@pytest.mark.parametrize("batch,queues,depth", [(1024, 2, 2), (37, 3, 1)])
-def test_queued_pipes_equal_one_pipe(dev, batch, queues, depth):
+@pytest.mark.parametrize("batch,queues,depth,pipes", [(1024, 2, 2, None), (37, 3, 1, None), (90, 2, 1, 4)])
+def test_queued_pipes_equal_one_pipe(dev, batch, queues, depth, pipes):
     """`QueuedHopPipelines` / `QueuedPipelinedStreams`: B streams as Q pipes on Q HIP streams, split hops (the 1,024-stream configuration: two
-    queues at depth 2).  Frames, hx, emitted hops and captured replays must equal ONE pipe of B streams bit for bit -- the generator is keyed by
+    queues at depth 2; four pipes taking turns on two queues).  Frames, hx, emitted hops and captured replays must equal ONE pipe of B streams bit for bit -- the generator is keyed by
     the global stream id, so sharding streams over queues changes nothing."""
     from audio_denoising_amd.pipeline import Denoiser, HopPipeline, PipelinedStream, QueuedHopPipelines, QueuedPipelinedStreams
     p = _params("S")
@@ -1402,7 +1402,8 @@ def test_queued_pipes_equal_one_pipe(dev, batch, queues, depth):
     for i in range(n):
         one.submit(frames[i], hx1, o1[i], seed=9, stream_id0=5)
     one.flush()
-    qp = QueuedHopPipelines(dn, batch, queues=queues, depth=depth)
+    qp = QueuedHopPipelines(dn, batch, queues=queues, depth=depth, pipes=pipes)
+    assert len(qp.pipes) == (pipes or queues) and len(qp.streams) == queues
     hx2 = dn.init_hx(batch)
     o2 = [torch.empty(batch, p.n_fft, device=dev) for _ in range(n)]
     qp.after()
@@ -1419,7 +1420,7 @@ def test_queued_pipes_equal_one_pipe(dev, batch, queues, depth):
     ps.set_depth(depth)
     a = torch.cat([ps.push(sig[:, i * p.hop:(i + 1) * p.hop].contiguous()) for i in range(n)] + [ps.flush()], 1)
     for captured in (False, True):
-        qs = QueuedPipelinedStreams(dn, batch, queues=queues, depth=depth, seed=3, stream_id0=7)
+        qs = QueuedPipelinedStreams(dn, batch, queues=queues, depth=depth, seed=3, stream_id0=7, pipes=pipes)
         hop = torch.empty(batch, p.hop, device=dev)
         out = torch.empty(batch, p.hop, device=dev)
         replay = qs.graph_steps(hop, out) if captured else None

@@ -18,6 +18,8 @@ run --batch 2048
 run --batch 2048 --queues 2 --depth 1
 run --batch 4096
 run --batch 8192
+run --batch 4096 --queues 2 --pipes 4 --depth 1     # pipes of 1,024 streams taking turns on two HIP streams
+run --batch 8192 --queues 2 --pipes 8 --depth 1
 run --stream --batch 256 --depth 4
 run --stream --depth 1 --batch 256                    # (device-fed at depth 1 and at 1,024 streams without the graph: what the host-fed lines compare with)
 run --stream --batch 1024
