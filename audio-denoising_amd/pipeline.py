@@ -317,6 +317,14 @@ class PipelinedStream(_Pipe):
         if init_angles is not None:
             # the slot buffers for injected phases are allocated by the first parity-mode launch: do that outside the capture
             self._warm_parity()
+        if isinstance(hop, (list, tuple)):             # K separate (B, hop) tensors instead of one (K, B, hop): the same K pushes
+            if not isinstance(out, (list, tuple)) or len(out) != len(hop) or (init_angles is not None and len(init_angles) != len(hop)):
+                raise ValueError("K hops need K outputs (and K sets of init_angles)")
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for k in range(len(hop)):
+                    self.push_(hop[k], out[k], None if init_angles is None else init_angles[k], check_weights=False)
+            return g
         if hop.dim() == 3 and (out.dim() != 3 or out.shape[0] != hop.shape[0] or (init_angles is not None and init_angles.shape[0] != hop.shape[0])):
             raise ValueError("K hops need K outputs (and K sets of init_angles)")
         g = torch.cuda.CUDAGraph()
@@ -517,12 +525,14 @@ class QueuedPipelinedStreams(_Queues):
         return torch.cat(parts, dim=0)
 
     def graph_steps(self, hop: torch.Tensor, out: torch.Tensor):
-        """One captured graph per queue (``PipelinedStream.graph_step`` of its row block of the (B, hop_length) tensors); returns ``replay()``,
-        which launches each graph on its queue."""
+        """One captured graph per pipe (``PipelinedStream.graph_step`` of its row block of the (B, hop_length) tensors -- or of K such tensors
+        each, given as lists: K pushes per graph); returns ``replay()``, which launches each graph on its queue."""
         graphs = []
+        many = isinstance(hop, (list, tuple))
         for pipe, st, lo, hi in self._each():
             with torch.cuda.stream(st):
-                graphs.append((pipe.graph_step(hop[lo:hi], out[lo:hi]), st))
+                graphs.append((pipe.graph_step([h[lo:hi] for h in hop], [o[lo:hi] for o in out]) if many
+                               else pipe.graph_step(hop[lo:hi], out[lo:hi]), st))
 
         def replay():
             for g, st in graphs:

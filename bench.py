@@ -237,6 +237,18 @@ def extra_measurements(args, dev, budget_steps=1500):
     el = time.perf_counter() - t0
     qs.flush()
     res["config5_stream_graph_1024"]["two_queues_depth2"] = {"value": round(B5 * n5 / el, 1), "unit": "frames/s", "ms_per_step": round(1e3 * el / n5, 4)}
+    # ... and eight pushes per captured graph and pipe
+    qs8 = QueuedPipelinedStreams(dn, B5, queues=2, depth=2)
+    replay8 = qs8.graph_steps([hops8[k] for k in range(K8)], [outs8[k] for k in range(K8)])
+    prewarm(replay8)
+    t0 = time.perf_counter()
+    for _ in range(n5 // K8):
+        replay8()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    qs8.flush()
+    res["config5_stream_graph_1024"]["two_queues_depth2"]["graph_of_8_hops"] = {"value": round(B5 * (n5 // K8) * K8 / el, 1), "unit": "frames/s",
+                                                                                "ms_per_step": round(1e3 * el / ((n5 // K8) * K8), 4)}
     # saturated regime (wavefront-per-stream Griffin-Lim)
     for b, n in ((1024, 300), (8192, 40)):
         v, ms = time_pipe(dn, b, dev, n, 1)

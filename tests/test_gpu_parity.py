@@ -1484,6 +1484,21 @@ def test_several_pushes_captured_as_one_graph_replay(dev):
     assert torch.equal(a, b) and a.abs().max().item() > 1e-3
     with pytest.raises(ValueError):
         ps.graph_step(hops, outs[0])
+    # the same K pushes from K separate tensors (lists): what the queued form captures per pipe
+    from audio_denoising_amd.pipeline import QueuedPipelinedStreams
+    qs = QueuedPipelinedStreams(dn, B, queues=2, depth=1, seed=3)
+    hl, ol = [torch.empty(B, p.hop, device=dev) for _ in range(K)], [torch.empty(B, p.hop, device=dev) for _ in range(K)]
+    replay = qs.graph_steps(hl, ol)
+    res = []
+    for r in range(4):
+        for k in range(K):
+            hl[k].copy_(sig[:, (r * K + k) * p.hop:(r * K + k + 1) * p.hop])
+        qs.after()
+        replay()
+        qs.before()
+        res += [ol[k].clone() for k in range(K)]
+    torch.cuda.synchronize()
+    assert torch.equal(a, torch.cat(res + [qs.flush()], 1))
 
 
 def test_captured_push_of_a_deep_pipe_replays(dev):
