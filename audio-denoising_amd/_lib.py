@@ -24,7 +24,7 @@ SYMBOLS = (
     "dn_model_create", "dn_model_destroy", "dn_cell_forward", "dn_cell_forward_ex", "dn_cell_forward_bf16", "dn_stft_general", "dn_server_rows", "dn_istft_general", "dn_dsp_create", "dn_dsp_destroy",
     "dn_dsp_get_tables", "dn_stft", "dn_stft_mel_log1p", "dn_mel_scale", "dn_invmel", "dn_residual_invmel",
     "dn_griffinlim", "dn_griffinlim_draw_phases", "dn_synthesis", "dn_istft", "dn_workspace_bytes", "dn_process_frame", "dn_stream_step",
-    "dn_pipe_create", "dn_pipe_destroy", "dn_pipe_set_model", "dn_pipe_set_head_start", "dn_pipe_set_gl_schedule", "dn_pipe_set_split", "dn_pipe_set_depth", "dn_pipe_reserve_parity", "dn_pipe_get_counters", "dn_pipe_submit", "dn_pipe_flush", "dn_pipe_stream_create", "dn_pipe_stream_push",
+    "dn_pipe_create", "dn_pipe_destroy", "dn_pipe_set_model", "dn_pipe_set_head_start", "dn_pipe_set_gl_schedule", "dn_pipe_set_split", "dn_pipe_set_depth", "dn_pipe_set_group", "dn_pipe_submit_group", "dn_pipe_stream_push_group", "dn_pipe_stream_flush_group", "dn_pipe_reserve_parity", "dn_pipe_get_counters", "dn_pipe_submit", "dn_pipe_flush", "dn_pipe_stream_create", "dn_pipe_stream_push",
     "dn_pipe_stream_flush", "dn_pipe_stream_push_host", "dn_pipe_stream_host_wait", "dn_pipe_stream_get_state", "dn_pipe_stream_set_state", "dn_momo_create", "dn_momo_destroy",
     "dn_momo_forward", "dn_last_error", "dn_abi_version",
 )
@@ -36,7 +36,7 @@ DN_GL_AUTO, DN_GL_WAVE_PER_COLUMN, DN_GL_WAVE_PER_STREAM = 0, 1, 2
 DN_HOST_STAGED = 1
 DN_HOST_DEFER = 2
 DN_SPLIT_AUTO, DN_SPLIT_OFF, DN_SPLIT_ON = -1, 0, 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class ModelCfg(C.Structure):
@@ -111,6 +111,11 @@ class DnLib:
         L.dn_pipe_set_gl_schedule.argtypes = [vp, i32]
         L.dn_pipe_set_split.argtypes = [vp, i32]
         L.dn_pipe_set_depth.argtypes = [vp, i32]
+        L.dn_pipe_set_group.argtypes = [vp, i32]
+        i64 = C.c_int64
+        L.dn_pipe_submit_group.argtypes = [vp, p, i64, p, p, i64, p, i64, u64, u64, i32, i32, f32, vp]
+        L.dn_pipe_stream_push_group.argtypes = [vp, p, i64, i32, p, i64, i32, p, i64, u64, u64, i32, f32, vp]
+        L.dn_pipe_stream_flush_group.argtypes = [vp, p, i64, i32, C.POINTER(i32), vp]
         L.dn_pipe_reserve_parity.argtypes = [vp]
         L.dn_pipe_get_counters.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(i32), vp]
         L.dn_pipe_submit.argtypes = [vp, p, p, p, p, u64, u64, i32, f32, vp]

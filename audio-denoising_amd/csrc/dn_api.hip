@@ -170,6 +170,9 @@ struct dn_pipe {
     float2* scratch_init = nullptr;                 // [n_slots] x the frame's initial phases [B][3][K] complex (allocated on first parity-mode use)
     float2* gl_state = nullptr;                     // [n_slots] x a parked Griffin-Lim chain ([B][3][2 NV + 2][64] complex: head start, chain segments)
     size_t slot_floats = 0, init_elems = 0, state_elems = 0;
+    int group = 0;                                  // hop groups (dn_pipe_set_group): hops a launch carries, 0 = single hops
+    unsigned long long group_pushes = 0;            // hops pushed into a streaming group pipe by this host (priming bookkeeping of *hops_valid)
+    int group_pending = 0;                          // frames the last group push fronted, as far as this host's own calls tell
     int gl_split = 0;                               // iterations of head start (0 = none)
     int gl_schedule = DN_GL_AUTO;                   // Griffin-Lim schedule of the back half (dn_pipe_set_gl_schedule)
     int split = DN_SPLIT_AUTO;                      // a hop as two launches, chains then front halves (dn_pipe_set_split)
@@ -938,6 +941,7 @@ void dn_pipe_destroy(dn_pipe* p) {
 
 int dn_pipe_set_head_start(dn_pipe* p, int32_t iterations) {
     if (!p || iterations < 0) return fail(DN_ERR_INVALID, "dn_pipe_set_head_start: bad argument");
+    if (iterations > 0 && p->group > 0) return fail(DN_ERR_INVALID, "dn_pipe_set_head_start: a group pipe never parks a chain");
     if (iterations > 0 && !p->gl_state) DN_HIP(hipMalloc(reinterpret_cast<void**>(&p->gl_state), p->n_slots * p->state_elems * sizeof(float2)));
     if (iterations > 0 && p->d->cfg.n_fft == 1536) {      // n_fft 1536: the front workgroup's spare wave draws the head start's initial phases into the slot
         int rc = dn_pipe_reserve_parity(p);
@@ -952,6 +956,7 @@ int dn_pipe_set_depth(dn_pipe* p, int32_t depth) {
     if (depth < 1 || depth > DN_PIPE_MAX_DEPTH) return fail(DN_ERR_INVALID, "dn_pipe_set_depth: depth must be in 1.." + std::to_string(DN_PIPE_MAX_DEPTH));
     if (depth > 1 && p->d->cfg.n_fft != 1024)
         return fail(DN_ERR_UNSUPPORTED, "pipes deeper than one hop are built for n_fft 1024 (at 1536 the per-lane state of a stream does not fit a wavefront's registers)");
+    if (depth > 1 && p->group > 0) return fail(DN_ERR_INVALID, "dn_pipe_set_depth: a group pipe runs whole chains per launch (dn_pipe_set_group(p, 0) first)");
     if (depth == p->depth) return DN_OK;
     // nothing may be in flight: the slots are re-laid out
     dn::PipeCtl h{};
@@ -981,6 +986,41 @@ int dn_pipe_set_depth(dn_pipe* p, int32_t depth) {
     h.slot_next = 0;
     DN_HIP(hipMemcpy(p->ctl, &h, sizeof(h), hipMemcpyHostToDevice));
     return dn_pipe_set_head_start(p, default_head_start(p));      // back to depth 1: the one-hop pipe's default head start again
+}
+
+int dn_pipe_set_group(dn_pipe* p, int32_t hops) {
+    if (!p) return fail(DN_ERR_INVALID, "dn_pipe_set_group: null pipe");
+    if (hops < 0 || hops > DN_PIPE_MAX_GROUP) return fail(DN_ERR_INVALID, "dn_pipe_set_group: hops must be in 0.." + std::to_string(DN_PIPE_MAX_GROUP));
+    if (hops > 0 && p->d->cfg.n_fft != 1024)
+        return fail(DN_ERR_UNSUPPORTED, "hop groups run whole Griffin-Lim chains one wavefront per stream, which is built for n_fft 1024");
+    if (hops > 0 && p->depth > 1) return fail(DN_ERR_INVALID, "dn_pipe_set_group: the pipe is deeper than one hop (dn_pipe_set_depth(p, 1) first)");
+    if (hops > 0 && p->hio) return fail(DN_ERR_UNSUPPORTED, "dn_pipe_set_group: the host-buffer transport moves single hops");
+    if (hops == p->group) return DN_OK;
+    // nothing may be in flight: the slots are re-laid out (two groups of the largest size: one being fronted, one whose chains run)
+    dn::PipeCtl h{};
+    DN_HIP(hipDeviceSynchronize());
+    DN_HIP(hipMemcpy(&h, p->ctl, sizeof(h), hipMemcpyDeviceToHost));
+    if (h.pending != 0) return fail(DN_ERR_INVALID, "dn_pipe_set_group: hops are in flight (flush first)");
+    const int n_slots = hops > 0 ? 2 * DN_PIPE_MAX_GROUP : p->depth + 1;
+    float* scratch = nullptr;
+    float2* init = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&scratch), n_slots * p->slot_floats * sizeof(float));
+    if (e == hipSuccess && p->scratch_init) e = hipMalloc(reinterpret_cast<void**>(&init), n_slots * p->init_elems * sizeof(float2));
+    if (e != hipSuccess) {
+        if (scratch) (void)hipFree(scratch);
+        if (init) (void)hipFree(init);
+        return fail(DN_ERR_HIP, std::string("dn_pipe_set_group: ") + hipGetErrorString(e));
+    }
+    (void)hipFree(p->scratch);
+    if (p->scratch_init) (void)hipFree(p->scratch_init);
+    if (p->gl_state) { (void)hipFree(p->gl_state); p->gl_state = nullptr; }
+    p->scratch = scratch; p->scratch_init = init;
+    p->n_slots = n_slots;
+    p->group = hops; p->group_pending = 0;
+    p->gl_split = 0;
+    h.slot_next = 0;
+    DN_HIP(hipMemcpy(p->ctl, &h, sizeof(h), hipMemcpyHostToDevice));
+    return hops > 0 ? DN_OK : dn_pipe_set_head_start(p, default_head_start(p));
 }
 
 int dn_pipe_set_gl_schedule(dn_pipe* p, int32_t schedule) {
@@ -1103,6 +1143,9 @@ static int fill_hop_args(dn_pipe* p, dn::HopArgs& a, const float* init_angles, u
     const bool can_split = per_stream && p->gl_split == 0;
     a.split = can_split && (p->split == DN_SPLIT_ON || (p->split == DN_SPLIT_AUTO && (long)p->B * p->depth >= dn::kSplitAutoChains)) ? 1 : 0;
     a.prime = p->d->cfg.n_fft / p->d->cfg.hop - 1;
+    if (p->group > 0) {          // whole chains: one workgroup a stream, wavefront j the j-th pending frame (group_kernel)
+        a.glw = 1; a.depth = 1; a.spb = 1; a.back_blocks = p->B; a.split = 0; a.gl_split = 0;
+    }
     return DN_OK;
 }
 
@@ -1110,6 +1153,7 @@ int dn_pipe_stream_push(dn_pipe* p, const void* hop_in, int32_t in_is_s16, void*
                         const float* init_angles, uint64_t seed, uint64_t stream_id0, int32_t n_iter, float momentum, void* stream) {
     if (!p || !p->ring) return fail(DN_ERR_INVALID, "dn_pipe_stream_push: not a streaming pipe");
     if (!hop_in || !hop_out) return fail(DN_ERR_INVALID, "dn_pipe_stream_push: null argument");
+    if (p->group > 0) return fail(DN_ERR_INVALID, "dn_pipe_stream_push: this pipe takes groups of hops (dn_pipe_stream_push_group)");
     dn::HopArgs a{};
     int rc = fill_hop_args(p, a, init_angles, seed, stream_id0, n_iter, momentum);
     if (rc != DN_OK) return rc;
@@ -1177,6 +1221,7 @@ int dn_pipe_stream_push_host(dn_pipe* p, const void* hop_in_host, int32_t in_is_
     HostIo* h = p->hio;
     hipStream_t cs = as_stream(stream);
     const size_t out_bytes = (size_t)p->B * p->d->cfg.hop * (out_is_s16 ? sizeof(short) : sizeof(float));
+    if (p->group > 0) return fail(DN_ERR_UNSUPPORTED, "dn_pipe_stream_push_host: the host-buffer transport moves single hops (dn_pipe_set_group(p, 0))");
     if (!(flags & DN_HOST_STAGED)) {
         // zero copy: page-locked host memory is in the device's address space.  The front workgroups read their stream's hop (1 KB) straight from it
         // and the Griffin-Lim workgroups store the emitted hop straight into it -- no copy engine, no second queue, no cross-queue event.
@@ -1264,6 +1309,7 @@ int dn_pipe_stream_host_wait(dn_pipe* p, uint64_t ticket) {
 int dn_pipe_stream_flush(dn_pipe* p, void* hop_out, int32_t out_is_s16, int32_t n_iter, float momentum, void* stream) {
     if (!p || !p->ring) return fail(DN_ERR_INVALID, "dn_pipe_stream_flush: not a streaming pipe");
     if (!hop_out) return fail(DN_ERR_INVALID, "dn_pipe_stream_flush: null argument");
+    if (p->group > 0) return fail(DN_ERR_INVALID, "dn_pipe_stream_flush: this pipe emits groups of hops (dn_pipe_stream_flush_group)");
     dn::HopArgs a{};
     int rc = fill_hop_args(p, a, nullptr, 0, 0, n_iter, momentum);
     if (rc != DN_OK) return rc;
@@ -1277,6 +1323,7 @@ int dn_pipe_submit(dn_pipe* p, const float* frames, float* hx, float* out, const
                    uint64_t stream_id0, int32_t n_iter, float momentum, void* stream) {
     if (!p || !frames || !hx || !out) return fail(DN_ERR_INVALID, "dn_pipe_submit: null argument");
     if (p->ring) return fail(DN_ERR_INVALID, "dn_pipe_submit: this is a streaming pipe (use dn_pipe_stream_push)");
+    if (p->group > 0) return dn_pipe_submit_group(p, frames, 0, hx, out, 0, init_angles, 0, seed, stream_id0, 1, n_iter, momentum, stream);
     dn::HopArgs a{};
     int rc = fill_hop_args(p, a, init_angles, seed, stream_id0, n_iter, momentum);
     if (rc != DN_OK) return rc;
@@ -1297,11 +1344,84 @@ int dn_pipe_flush(dn_pipe* p, int32_t n_iter, float momentum, void* stream) {
     int rc = fill_hop_args(p, a, nullptr, 0, 0, n_iter, momentum);
     if (rc != DN_OK) return rc;
     a.front_B = 0;
+    if (p->group > 0) {                             // one launch: the whole chains of the group in flight
+        dn::launch_group(p->d->view, p->bs->view, a, p->bf16, as_stream(stream));
+        return check_launch("group_kernel(flush)");
+    }
     for (int i = 0; i < p->depth; ++i) {            // every launch advances each hop in flight by one chain segment
         dn::launch_hop(p->d->view, p->bs->view, a, p->bf16, as_stream(stream));
         rc = check_launch("hop_kernel(flush)");
         if (rc != DN_OK) return rc;
     }
+    return DN_OK;
+}
+
+int dn_pipe_submit_group(dn_pipe* p, const float* frames, int64_t frames_stride, float* hx, float* out, int64_t out_stride,
+                         const float* init_angles, int64_t init_stride, uint64_t seed, uint64_t stream_id0, int32_t hops,
+                         int32_t n_iter, float momentum, void* stream) {
+    if (!p || !frames || !hx || !out) return fail(DN_ERR_INVALID, "dn_pipe_submit_group: null argument");
+    if (p->ring) return fail(DN_ERR_INVALID, "dn_pipe_submit_group: this is a streaming pipe (use dn_pipe_stream_push_group)");
+    if (p->group <= 0) return fail(DN_ERR_INVALID, "dn_pipe_submit_group: not a group pipe (dn_pipe_set_group)");
+    if (hops < 1 || hops > p->group) return fail(DN_ERR_INVALID, "dn_pipe_submit_group: hops must be in 1.." + std::to_string(p->group));
+    if (frames_stride < 0 || out_stride < 0 || init_stride < 0) return fail(DN_ERR_INVALID, "dn_pipe_submit_group: negative stride");
+    const int64_t line = (int64_t)p->B * p->d->cfg.n_fft;
+    if (hops > 1 && out_stride < line) return fail(DN_ERR_INVALID, "dn_pipe_submit_group: the output frames of a group overlap (out_stride < B * n_fft)");
+    dn::HopArgs a{};
+    int rc = fill_hop_args(p, a, init_angles, seed, stream_id0, n_iter, momentum);
+    if (rc != DN_OK) return rc;
+    a.front_B = p->B; a.frames = frames; a.hx = hx; a.gl_out = out;
+    a.group_hops = hops; a.frames_stride = frames_stride; a.out_stride = out_stride; a.init_in_stride = init_stride;
+    dn::launch_group(p->d->view, p->bs->view, a, p->bf16, as_stream(stream));
+    rc = check_launch("group_kernel");
+    if (rc != DN_OK) return rc;
+    p->submitted = true;
+    return DN_OK;
+}
+
+int dn_pipe_stream_push_group(dn_pipe* p, const void* hop_in, int64_t in_stride, int32_t in_is_s16, void* hop_out, int64_t out_stride,
+                              int32_t out_is_s16, const float* init_angles, int64_t init_stride, uint64_t seed, uint64_t stream_id0,
+                              int32_t n_iter, float momentum, void* stream) {
+    if (!p || !p->ring) return fail(DN_ERR_INVALID, "dn_pipe_stream_push_group: not a streaming pipe");
+    if (!hop_in || !hop_out) return fail(DN_ERR_INVALID, "dn_pipe_stream_push_group: null argument");
+    if (p->group <= 0) return fail(DN_ERR_INVALID, "dn_pipe_stream_push_group: not a group pipe (dn_pipe_set_group)");
+    const int64_t row = (int64_t)p->B * p->d->cfg.hop;
+    if (in_stride < 0 || init_stride < 0 || (p->group > 1 && out_stride < row))
+        return fail(DN_ERR_INVALID, "dn_pipe_stream_push_group: bad stride (the emitted hops of a group must not overlap)");
+    dn::HopArgs a{};
+    int rc = fill_hop_args(p, a, init_angles, seed, stream_id0, n_iter, momentum);
+    if (rc != DN_OK) return rc;
+    a.front_B = p->B; a.hx = p->hx;
+    a.hop_in = hop_in; a.ring = p->ring; a.in_s16 = in_is_s16;
+    a.ola = p->ola; a.hop_out = hop_out; a.out_s16 = out_is_s16;
+    a.group_hops = p->group; a.group_out = p->group; a.filler_first = 1;
+    a.hop_in_stride = in_stride; a.hop_out_stride = out_stride; a.init_in_stride = init_stride;
+    dn::launch_group(p->d->view, p->bs->view, a, p->bf16, as_stream(stream));
+    rc = check_launch("group_kernel(stream)");
+    if (rc != DN_OK) return rc;
+    const unsigned long long before = p->group_pushes;
+    p->group_pushes += (unsigned long long)p->group;
+    const unsigned long long prime = (unsigned long long)a.prime;
+    const unsigned long long primed_before = before < prime ? before : prime, primed_after = p->group_pushes < prime ? p->group_pushes : prime;
+    p->group_pending = p->group - (int)(primed_after - primed_before);
+    return DN_OK;
+}
+
+int dn_pipe_stream_flush_group(dn_pipe* p, void* hop_out, int64_t out_stride, int32_t out_is_s16, int32_t* hops_valid, void* stream) {
+    if (!p || !p->ring) return fail(DN_ERR_INVALID, "dn_pipe_stream_flush_group: not a streaming pipe");
+    if (!hop_out) return fail(DN_ERR_INVALID, "dn_pipe_stream_flush_group: null argument");
+    if (p->group <= 0) return fail(DN_ERR_INVALID, "dn_pipe_stream_flush_group: not a group pipe (dn_pipe_set_group)");
+    if (p->group > 1 && out_stride < (int64_t)p->B * p->d->cfg.hop) return fail(DN_ERR_INVALID, "dn_pipe_stream_flush_group: the emitted hops overlap");
+    dn::HopArgs a{};
+    int rc = fill_hop_args(p, a, nullptr, 0, 0, 0, 0.0f);
+    if (rc != DN_OK) return rc;
+    a.front_B = 0;
+    a.ola = p->ola; a.hop_out = hop_out; a.out_s16 = out_is_s16;
+    a.group_hops = 0; a.group_out = p->group; a.filler_first = 0; a.hop_out_stride = out_stride;
+    dn::launch_group(p->d->view, p->bs->view, a, p->bf16, as_stream(stream));
+    rc = check_launch("group_kernel(stream flush)");
+    if (rc != DN_OK) return rc;
+    if (hops_valid) *hops_valid = p->group_pending;
+    p->group_pending = 0;
     return DN_OK;
 }
 

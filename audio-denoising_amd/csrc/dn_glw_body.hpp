@@ -69,7 +69,16 @@ __device__ __forceinline__ void glw_fill_tables(char* smem, const DspDev& d, int
 //                the previous rebuilt spectrum, 17.5 KB a stream in 16-byte rows instead of gl_body's 27.6 KB in 8-byte rows.  Every launch of a
 //                deep pipe moves this through HBM for every stream and segment boundary, all CUs at once, at the head of the launch.
 constexpr int kGlwFresh = 0, kGlwFromX = 1, kGlwFromSeg = 2;
-template <int NFFT, bool STREAM>
+// EMIT: what the wave does with a finished frame:
+//   kEmitFrame   store it (frame mode);
+//   kEmitStream  fold it into the stream's overlap-add line and emit the hop (P12; one chain a stream and launch);
+//   kEmitStage   leave frame x 1/envelope in the wave's LDS line: the workgroup folds the frames of its stream in order afterwards (hop groups:
+//                several chains of ONE stream finish in the same launch and the overlap-add line is sequential)
+constexpr int kEmitFrame = 0, kEmitStream = 1, kEmitStage = 2;
+template <int NFFT> __device__ __forceinline__ float* glw_signal_line(char* smem, int wv) {
+    return reinterpret_cast<float*>(smem + GlwLds<NFFT>::kWave + wv * GlwLds<NFFT>::kPerWave + 8 * 2 * Geo<NFFT>::kTile);
+}
+template <int NFFT, int EMIT>
 __device__ __forceinline__ void glw_body(char* smem, const DspDev& d, const float* __restrict__ mag, const v2f* __restrict__ init,
                                          uint64_t seed, uint64_t sid0, const float* __restrict__ scale, float* __restrict__ wave,
                                          int n_iter, float mom, size_t b, int lane, int wv, float* ola, void* hop_out, int out_s16,
@@ -312,8 +321,18 @@ __device__ __forceinline__ void glw_body(char* smem, const DspDev& d, const floa
 
     DN_WSTAMP(5);
     // ---- final istft: divide by the window envelope, trim, scale (app3.py:217 `* peak`); streaming: fold into the overlap-add line (P12)
+    if (EMIT == kEmitStage) {
+        wave_sync();
+#pragma unroll
+        for (int t = 0; t < kNV; ++t) {
+            const int n = 2 * (lane + 64 * t);
+            const v2f e = *reinterpret_cast<const v2f*>(d.inv_env + n);
+            *reinterpret_cast<v2f*>(sl + n) = mk2(snew[t][0] * e[0], snew[t][1] * e[1]);          // the rounded product the fold's fma takes (as below)
+        }
+        return;
+    }
     const float sc = scale != nullptr ? scale[b] : 1.0f;
-    if (!STREAM) {
+    if (EMIT == kEmitFrame) {
 #pragma unroll
         for (int t = 0; t < kNV; ++t) {
             const int n = 2 * (lane + 64 * t);

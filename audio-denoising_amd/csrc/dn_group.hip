@@ -1,0 +1,173 @@
+// dn_group.hip -- hop groups: H consecutive hops of every stream in ONE launch, every Griffin-Lim chain whole (dn_pipe_set_group).
+#include "dn_hop_common.hpp"
+
+namespace dn {
+
+// ---- hop groups: the whole Griffin-Lim chain of a frame inside ONE launch (dn_pipe_set_group; n_fft 1024)
+// The deep pipe above keeps D hops of a stream in flight by cutting every chain into D segments, one per launch -- and pays for it at every
+// launch boundary: the chains park in HBM (17.5 KB a stream and boundary, all CUs fetching theirs in the same microsecond at the head of the next
+// launch: ~10 % of a launch, 17x the path's compulsory traffic).  Nothing but a launch boundary forces a chain off the chip, so a launch here is as
+// long as a chain: it carries H consecutive new hops of every stream -- their front halves one after the other in the stream's front workgroup,
+// hx handed from hop to hop -- beside the WHOLE chains of the H hops the previous launch fronted, one wavefront each.  A chain is never cut, nothing
+// is parked, a frame's phases are drawn by its own chain wave; between launches only the slots travel (magnitudes, peak, meta: 6.5 KB a frame).
+//   blocks [0, back_B)           stream b's pending frames: wavefront j runs the chain of the j-th oldest one from its first iteration to its last
+//   blocks [back_B, back_B + B)  P1-P10 of stream b's `group_hops` new hops, in order, into slots slot_next, slot_next + 1, ...
+// Same arithmetic, same seeds (seed + frame index, stream id), same slots as the one-hop pipe: frames, hx and emitted hops are bit-identical to it.
+// The price is granularity, not latency: input arrives H hops at a time and a frame is complete one launch (H hops) after its group was submitted.
+template <int NFFT, bool STREAM, bool BF16, int CT>
+__global__ __launch_bounds__(kHopPipeThreads, 2) void group_kernel(DspDev d, CellDev cd, HopArgs a) {
+    static_assert(NFFT == 1024, "whole chains run one wavefront per stream (dn_glw_body.hpp): n_fft 1024");
+    constexpr int kNR = NFFT, kBins = Geo<NFFT>::kBins, kHop = kNR / 2;
+    static_assert(kHopPipeThreads * 2 == kHop, "the ordered overlap-add fold: one sample pair of either half of the line per thread");
+    __shared__ __attribute__((aligned(16))) char smem[hop_smem<NFFT>()];
+    const int tid = threadIdx.x;
+    const unsigned long long pushes = a.ctl->pushes, frames = a.ctl->frames;
+    const unsigned int pending = a.ctl->pending, slot_next = a.ctl->slot_next;
+    const SlotLayout sl(a.B, d.n_mels, kBins);
+    // new hops that only fill the ring (the first n_fft / hop - 1 pushes of a stream, app3.py:174-178), the others are fronted
+    int prime_hops = 0;
+    if (STREAM) {
+        const long long left = (long long)a.prime - (long long)pushes;
+        prime_hops = left <= 0 ? 0 : left < (long long)a.group_hops ? (int)left : a.group_hops;
+    }
+    const int fronted = a.front_B > 0 ? a.group_hops - prime_hops : 0;
+    if ((int)blockIdx.x < a.back_blocks) {
+        const size_t b = blockIdx.x;
+        const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const bool runs = wv < (int)pending;
+        if (pending && !runs) {            // (the workgroup's window tables: every wave fills its share; a wave with a chain does it inside glw_body)
+            glw_fill_tables<NFFT, kHopPipeThreads>(smem, d, tid);
+            DN_LDS_BARRIER();
+        }
+        if (runs) {
+            const int s = slot_behind(slot_next, (int)pending - wv, a.n_slots);
+            const float* slot = a.slots + (size_t)s * a.slot_stride;
+            const uint32_t* meta = reinterpret_cast<const uint32_t*>(slot + sl.meta) + kSlotMeta * b;
+            const v2f* init = meta[0] ? reinterpret_cast<const v2f*>(a.slot_init + (size_t)s * a.init_stride) : nullptr;
+            const uint64_t seed = (uint64_t)meta[1] | ((uint64_t)meta[2] << 32);
+            const uint64_t sid0 = (uint64_t)meta[3] | ((uint64_t)meta[4] << 32);
+            const int n_iter = __builtin_amdgcn_readfirstlane((int)meta[6]);
+            const float mom = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane((int)meta[7]));
+            float* gl_out = reinterpret_cast<float*>((uint64_t)meta[8] | ((uint64_t)meta[9] << 32));
+            glw_body<NFFT, STREAM ? kEmitStage : kEmitFrame>(smem, d, slot + sl.lin, init, seed, sid0, slot + sl.peak, gl_out, n_iter, mom, b, lane, wv,
+                                                             nullptr, nullptr, 0, 0, -1, kGlwFresh, nullptr, tid);
+        }
+        if (STREAM) {
+            // P12 for the frames of this stream in order: hop_out <- ola[:hop]; ola <- concat(ola[hop:], 0) + frame * peak (app3.py:217-224).  The chains
+            // left frame x 1/envelope in their LDS lines; a thread owns one sample pair of either half of the line and keeps both in registers.
+            __syncthreads();
+            float* orow = a.ola + b * kNR;
+            const int n = 2 * tid, P = (int)pending;
+            const int lead = a.filler_first ? a.group_out - P : 0;          // hops with no frame behind them: zero, as the reference's ola still is
+            v2f lo = *reinterpret_cast<const v2f*>(orow + n), hi = *reinterpret_cast<const v2f*>(orow + n + kHop);
+            for (int i = 0; i < a.group_out; ++i) {
+                const int f = i - lead;
+                v2f emit = mk2(0.0f, 0.0f);
+                if (f >= 0 && f < P) {
+                    emit = lo;
+                    const float* line = glw_signal_line<NFFT>(smem, f);
+                    const v2f p0 = *reinterpret_cast<const v2f*>(line + n), p1 = *reinterpret_cast<const v2f*>(line + n + kHop);
+                    const float sc = (a.slots + (size_t)slot_behind(slot_next, P - f, a.n_slots) * a.slot_stride + sl.peak)[b];
+                    lo = mk2(fmaf(p0[0], sc, hi[0]), fmaf(p0[1], sc, hi[1]));
+                    hi = mk2(fmaf(p1[0], sc, 0.0f), fmaf(p1[1], sc, 0.0f));
+                }
+                const size_t at = (size_t)i * (size_t)a.hop_out_stride + b * kHop + n;
+                if (a.out_s16) {
+                    const float c0 = fminf(fmaxf(emit[0], -1.0f), 1.0f) * 32767.0f, c1 = fminf(fmaxf(emit[1], -1.0f), 1.0f) * 32767.0f;   // app3.py:244-245
+                    *reinterpret_cast<unsigned int*>(static_cast<short*>(a.hop_out) + at) = (unsigned int)(unsigned short)(short)c0 | ((unsigned int)(unsigned short)(short)c1 << 16);
+                } else {
+                    *reinterpret_cast<v2f*>(static_cast<float*>(a.hop_out) + at) = emit;
+                }
+            }
+            if (P > 0) {
+                *reinterpret_cast<v2f*>(orow + n) = lo;
+                *reinterpret_cast<v2f*>(orow + n + kHop) = hi;
+            }
+        }
+    } else {
+        const size_t b = blockIdx.x - a.back_blocks;
+#pragma unroll 1
+        for (int h = 0; h < a.group_hops; ++h) {
+            // One hop of the loop is three large straight-line stages.  Everything they read through the plan's pointers is loop-invariant, and hoisted
+            // out of the loop it would all be live at once (every table pointer, the lane's twiddles, weight fragments: ~190 VGPRs and ~300 SGPRs of
+            // spills): the pointers of each hop are rebased by a zero the compiler cannot see through, so each stage loads what it needs where it
+            // needs it, as in the single-hop kernels.
+            int z;
+            DN_OPAQUE_ZERO(z);
+            const DspDev dz = rebase(d, z);
+            const CellDev cz = rebase(cd, z);
+            const int tidz = tid + z;
+            const float* frames_in = STREAM ? a.ring : a.frames + (size_t)h * (size_t)a.frames_stride;
+            if (STREAM) {
+                const char* in = static_cast<const char*>(a.hop_in) + (size_t)h * (size_t)a.hop_in_stride * (a.in_s16 ? 2 : 4);
+                ring_shift<NFFT, kHopPipeThreads>(a.ring, in, a.in_s16, b, tid);
+            }
+            if (h < prime_hops) continue;
+            const int q = h - prime_hops;
+            int s = (int)slot_next + q;
+            if (s >= a.n_slots) s -= a.n_slots;
+            float* slot = a.slots + (size_t)s * a.slot_stride;
+            stft_body<NFFT, false, true, kHopPipeThreads>(smem, dz, frames_in, nullptr, slot, slot + sl.peak, DN_PEAK_NORMALIZE | DN_PRE_WINDOW, b, tidz);   // P1-P6
+            __syncthreads();
+            cell_body<kHopPipeThreads / 64, BF16, CT>(smem, cz, slot, a.hx + z, slot + sl.diff, a.hx + z, 3, a.C, b, tidz);                               // P7
+            __syncthreads();
+            invmel_body<NFFT, true, kHopPipeThreads>(smem, dz, slot, slot + sl.diff, slot + sl.lin, 3 * a.B, b * 3, tidz);                              // P8-P10
+            if (tid == 0) {
+                uint32_t* meta = reinterpret_cast<uint32_t*>(slot + sl.meta) + kSlotMeta * b;
+                const uint64_t seed = a.seed + frames + (unsigned long long)q;
+                meta[0] = a.init_in != nullptr ? 1u : 0u;
+                meta[1] = (uint32_t)seed;
+                meta[2] = (uint32_t)(seed >> 32);
+                meta[3] = (uint32_t)a.sid0;
+                meta[4] = (uint32_t)(a.sid0 >> 32);
+                meta[5] = 0u;
+                meta[6] = (uint32_t)a.n_iter;
+                meta[7] = __builtin_bit_cast(uint32_t, a.mom);
+                const uint64_t dst = reinterpret_cast<uint64_t>(STREAM ? nullptr : a.gl_out + (size_t)h * (size_t)a.out_stride);
+                meta[8] = (uint32_t)dst;
+                meta[9] = (uint32_t)(dst >> 32);
+            }
+            if (a.init_in != nullptr) {
+                const float2* src = reinterpret_cast<const float2*>(a.init_in + (size_t)h * (size_t)a.init_in_stride) + b * 3 * kBins;
+                float2* dst = a.slot_init + (size_t)s * a.init_stride + b * 3 * kBins;
+                for (int i = tid; i < 3 * kBins; i += kHopPipeThreads) dst[i] = src[i];
+            }
+            __syncthreads();          // the next hop reuses the LDS stages and reads the hx this one stored
+        }
+    }
+    // ---- ticket: the last workgroup of the launch advances the control block (every workgroup has read it by then)
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned int t = atomicAdd(&a.ctl->done, 1u);
+        if (t == gridDim.x - 1) {
+            a.ctl->done = 0;
+            a.ctl->launches = a.ctl->launches + 1;
+            if (a.front_B > 0) a.ctl->pushes = pushes + (unsigned long long)a.group_hops;
+            a.ctl->frames = frames + (unsigned long long)fronted;
+            unsigned int sn = slot_next + (unsigned int)fronted;
+            if (sn >= (unsigned int)a.n_slots) sn -= (unsigned int)a.n_slots;
+            a.ctl->slot_next = sn;
+            a.ctl->pending = (unsigned int)fronted;          // every pending chain ran to its end in this launch
+        }
+    }
+}
+
+void launch_group(const DspDev& d, const CellDev& c, const HopArgs& a, bool bf16, hipStream_t st) {
+    const dim3 grid(a.back_blocks + a.front_B), block(kHopPipeThreads);
+#ifdef DN_GROUP_ONE          // (experiment builds: one instantiation)
+    hipLaunchKernelGGL((group_kernel<1024, false, false, 5>), grid, block, 0, st, d, c, a);
+    return;
+#endif
+    const bool stream = a.ola != nullptr;
+    const bool usual = a.C == 5;
+    auto go = [&](auto k) { hipLaunchKernelGGL(k, grid, block, 0, st, d, c, a); };
+    if (stream) {
+        if (usual) { if (bf16) go(group_kernel<1024, true, true, 5>); else go(group_kernel<1024, true, false, 5>); }
+        else { if (bf16) go(group_kernel<1024, true, true, 0>); else go(group_kernel<1024, true, false, 0>); }
+    } else {
+        if (usual) { if (bf16) go(group_kernel<1024, false, true, 5>); else go(group_kernel<1024, false, false, 5>); }
+        else { if (bf16) go(group_kernel<1024, false, true, 0>); else go(group_kernel<1024, false, false, 0>); }
+    }
+}
+
+}  // namespace dn

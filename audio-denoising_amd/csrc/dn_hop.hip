@@ -17,70 +17,9 @@
 //   What changes from hop to hop -- the slot parity, the Griffin-Lim seed, whether a hop is pending, the ring priming
 //   of a new stream -- lives in a device-resident control block (PipeCtl) that the last workgroup of every launch
 //   advances, so one captured launch replays indefinitely under hipGraph (BASELINE config 5).
-#include "dn_cell_body.hpp"
-#include "dn_gl_body.hpp"
-#include "dn_glw_body.hpp"
-#include "dn_invmel_body.hpp"
-#include "dn_stft_body.hpp"
+#include "dn_hop_common.hpp"
 
 namespace dn {
-
-constexpr int kHopThreads = 192;          // the Griffin-Lim chain: one wavefront per STFT column
-constexpr int kHopPipeThreads = 256;      // workgroup size of the fused launches: a fourth wavefront for the front half
-#ifndef DN_GL_PRIO
-#define DN_GL_PRIO 3
-#endif
-#ifndef DN_HS_PRIO
-#define DN_HS_PRIO 1
-#endif
-constexpr int cmax(int a, int b) { return a > b ? a : b; }
-template <int NFFT> constexpr int hop_smem() {
-    return cmax(cmax(cmax(kCellSmem, gl_smem<NFFT>()), cmax(stft_smem<NFFT>(), kInvSmem)), NFFT == 1024 ? glw_smem<1024>() : 0);
-}
-template <int NFFT> constexpr int front_smem() { return cmax(cmax(kCellSmemUnstaged, stft_smem<NFFT>()), kInvSmem); }    // 35 KB: four a CU
-static_assert(kHopThreads == kGlThreads && kHopThreads == kStftThreads && kHopThreads == kInvThreads, "one block size for all bodies");
-
-// ring <- concat(ring[hop:], hop_in): every thread holds its float4s before anything is overwritten   (app3.py:174,226)
-template <int NFFT, int THREADS = kHopThreads>
-__device__ __forceinline__ void ring_shift(float* ring, const void* hop_in, int in_s16, size_t b, int tid) {
-    constexpr int kNR = NFFT, kLine4 = kNR / 4, kHop4 = kNR / 8;
-    static_assert(kLine4 <= 2 * THREADS, "two float4 per thread cover the line");
-    float4* r4 = reinterpret_cast<float4*>(ring + b * kNR);
-    float4 v[2];
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int i4 = tid + THREADS * r;
-        v[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i4 < kLine4 - kHop4) v[r] = r4[i4 + kHop4];
-        else if (i4 < kLine4) {
-            const int j4 = i4 - (kLine4 - kHop4);
-            if (in_s16) {      // int16 -> float32 / iinfo(int16).max   (app3.py:172)
-                const short4 q = reinterpret_cast<const short4*>(static_cast<const short*>(hop_in) + b * (kNR / 2))[j4];
-                v[r] = make_float4((float)q.x / 32767.0f, (float)q.y / 32767.0f, (float)q.z / 32767.0f, (float)q.w / 32767.0f);
-            } else {
-                v[r] = reinterpret_cast<const float4*>(static_cast<const float*>(hop_in) + b * (kNR / 2))[j4];
-            }
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int i4 = tid + THREADS * r;
-        if (i4 < kLine4) r4[i4] = v[r];
-    }
-    __syncthreads();
-}
-
-// offsets (in floats) of the parts of a scratch slot.  meta: kSlotMeta u32 per stream, written by the frame's front workgroup and read by its
-// Griffin-Lim workgroup in the next launch -- everything the pending hop is finished with is the FRAME's own, not the next call's:
-//   [0] has injected phases  [1,2] Griffin-Lim seed  [3,4] stream id of stream 0  [5] head-start iterations already run
-//   [6] n_iter  [7] momentum / (1 + momentum) (bits)  [8,9] where the frame goes (frame mode: the `out` of its dn_pipe_submit)
-struct SlotLayout {
-    size_t diff, peak, meta, lin;
-    __host__ __device__ SlotLayout(int B, int M, int K) {
-        diff = (size_t)B * 3 * M; peak = 2 * diff; meta = peak + B; lin = meta + kSlotMeta * (size_t)B; (void)K;
-    }
-};
 
 // n_fft 1536: the Griffin-Lim body would take 330 registers and shut the front workgroup out of the CU; capping the
 // kernel at two waves per SIMD (256 registers, ~80 values spilled to scratch) keeps both halves resident (+30 % at 1024
@@ -99,13 +38,6 @@ static __device__ unsigned int g_hop_blk_hw[2048];          // where every workg
 #else
 #define DN_HSTAMP(id) do { } while (0)
 #endif
-
-// slot of the frame that is `back` frames behind the next one (slot_next is the slot the next front half writes)
-__device__ __forceinline__ int slot_behind(unsigned int slot_next, int back, int n_slots) {
-    int s = (int)slot_next - back;
-    while (s < 0) s += n_slots;
-    return s;
-}
 
 // CT: the number of compressed mel bins when the plan has the usual one (80 mels at n_fft 1024, 64 at 1536), 0 = any (run-time lengths in the model)
 // GLW: the pending hops' Griffin-Lim runs one wavefront per stream and chain segment (dn_glw_body.hpp) instead of one wavefront per column (one
@@ -321,6 +253,11 @@ __global__ __launch_bounds__(kHopPipeThreads, FRONT ? kFrontPerCu : (NFFT == 153
         }
     }
     // ---- ticket: the last workgroup of the launch advances the control block (every workgroup has read it by then)
+    // Zero-copy host transport: the completion word the last workgroup publishes must not overtake ANY workgroup's samples.  A workgroup barrier
+    // orders LDS and (in this wave-sharing mode) does not have to wait for outstanding stores, and stores of different workgroups reach the host
+    // through different L2s: so every wave first waits until its own stores are acknowledged, and the ticket is a release / acquire pair at system
+    // scope -- each workgroup's samples happen-before its increment, every increment happens-before the last workgroup's publication.
+    if (a.host_done != nullptr) DN_WAIT_VMEM();
     __syncthreads();
 #ifdef DN_PROBE
     if (tid == 0 && blockIdx.x < 2048) {
@@ -330,9 +267,8 @@ __global__ __launch_bounds__(kHopPipeThreads, FRONT ? kFrontPerCu : (NFFT == 153
     }
 #endif
     if (tid == 0) {
-        // (zero-copy host transport: this workgroup's stores to host memory are uncached writes that every wave waited out (vmcnt) at the barrier
-        // above; they are posted ahead of whatever the last workgroup publishes after the ticket below -- no L2 write-back per workgroup)
-        const unsigned int t = atomicAdd(&a.ctl->done, 1u);
+        const unsigned int t = a.host_done != nullptr ? __hip_atomic_fetch_add(&a.ctl->done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_SYSTEM)
+                                                      : atomicAdd(&a.ctl->done, 1u);
         if (t == gridDim.x - 1) {
             a.ctl->done = 0;
             if (!FRONT) a.ctl->launches = launches + 1;     // (the chains' launch of a split hop has counted it: this one is launch `launches - 1` still)

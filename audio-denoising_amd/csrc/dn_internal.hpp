@@ -29,6 +29,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define DN_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #endif
 
+// Every vector-memory operation of the calling wave has completed (loads returned, stores acknowledged).
+#ifndef DN_WAIT_VMEM
+#define DN_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#endif
+
 // Wave-wide max / sum, the result in every lane.  On the device: six DPP steps on the VALU (row_shr 1, 2, 4, 8, then the row
 // broadcasts 15 and 31 leave the total in lane 63) -- __shfl_xor compiles to ds_bpermute, an LDS round trip of ~230 cycles a step.
 // (DN_WAVE_REDUCE_SHFL selects the __shfl_xor form, for a build whose target has no DPP.)
@@ -170,9 +175,18 @@ struct HopArgs {
     // moves that stream's row (host_copy_n16 / B 16-byte units) to that push's page-locked buffer before it starts on its own hop, so the PCIe
     // writes overlap the hop instead of ending it as one burst (null = nothing to move; only launches with front workgroups carry one)
     const uint4* host_copy_src; uint4* host_copy_dst; unsigned int host_copy_n16;
+    // hop groups (group_kernel; dn_pipe_set_group): ONE launch carries `group_hops` consecutive new hops of every stream (their front halves run one
+    // after the other in the stream's front workgroup, hx carried) and the WHOLE Griffin-Lim chains of the hops the previous launch fronted, one
+    // wavefront each -- no chain is ever parked.  Hop h of the group reads frames + h * frames_stride (hop_in + h * hop_in_stride when streaming),
+    // takes its injected phases from init_in + h * init_in_stride and is written to gl_out + h * out_stride; a streaming launch emits `group_out`
+    // hops at hop_out + i * hop_out_stride (strides in elements of the respective type); filler_first: hops without a frame behind them (start of a
+    // stream) are the leading ones of a push and the trailing ones of a flush
+    int group_hops, group_out, filler_first;
+    long long frames_stride, out_stride, init_in_stride, hop_in_stride, hop_out_stride;
 };
 void launch_host_copy(const uint4* src, uint4* dst, unsigned int n16, unsigned long long* done, unsigned long long value, hipStream_t st);
 void launch_hop(const DspDev& d, const CellDev& c, const HopArgs& a, bool bf16, hipStream_t st);
+void launch_group(const DspDev& d, const CellDev& c, const HopArgs& a, bool bf16, hipStream_t st);
 void launch_ctl_set(PipeCtl* ctl, unsigned long long pushes, unsigned long long frames, unsigned int pending, hipStream_t st);
 
 // The whole hop for one batch in ONE launch, nothing overlapped (dn_process_frame / dn_stream_step).

@@ -185,6 +185,7 @@ class _Pipe:
         if hs is not None:
             self.lib.check(self.lib.dn_pipe_set_head_start(handle, int(hs)))
         self.depth = 1
+        self.group = 0
         dp = os.environ.get("DN_PIPE_DEPTH")           # likewise: hops of one stream in flight
         if dp is not None:
             self.set_depth(int(dp))
@@ -213,6 +214,14 @@ class _Pipe:
         with torch.cuda.device(self.dn.device):
             self.lib.check(self.lib.dn_pipe_set_depth(self.handle, int(depth)))
         self.depth = int(depth)
+
+    def set_group(self, hops: int) -> None:
+        """dn_pipe_set_group: a launch carries ``hops`` (1 .. 4; 0 = back to single hops) CONSECUTIVE hops of every stream -- their front halves in
+        order, hx handed on -- beside the WHOLE Griffin-Lim chains of the hops the previous launch fronted (one wavefront each): no chain is ever
+        parked between launches.  Same frames, hx and samples as the one-hop pipe, bit for bit; n_fft 1024.  Call while nothing is in flight."""
+        with torch.cuda.device(self.dn.device):
+            self.lib.check(self.lib.dn_pipe_set_group(self.handle, int(hops)))
+        self.group = int(hops)
 
     def set_head_start(self, iterations: int) -> None:
         """dn_pipe_set_head_start: Griffin-Lim iterations a front workgroup runs of its own frame's chain (0 = off)."""
@@ -261,6 +270,37 @@ class HopPipeline(_Pipe):
             if keep is not None and not torch.cuda.is_current_stream_capturing():
                 keep.record_stream(torch.cuda.current_stream())     # the launch copies the phases into its scratch slot
 
+    def submit_group(self, frames: torch.Tensor, hx: torch.Tensor, out: torch.Tensor, seed: int = 0, stream_id0: int = 0,
+                     init_angles: torch.Tensor | None = None, check_weights: bool = True) -> None:
+        """``frames`` / ``out`` of shape ``(H, B, n_fft)``, H <= the pipe's group size (``set_group``): H consecutive hops of every stream
+        in ONE launch (dn_pipe_submit_group).  ``hx`` is advanced through all H; ``out`` is complete after the next ``submit_group`` or
+        ``flush``.  ``init_angles`` (parity mode): ``(H, B, K, 3)`` complex64.  The f-th frame of the pipe draws from ``seed + f``."""
+        d = self.dn
+        if frames.dim() != 3 or tuple(out.shape) != tuple(frames.shape) or frames.shape[1:] != (self.batch, d.n_fft):
+            raise ValueError(f"frames and out must both be (H, {self.batch}, {d.n_fft})")
+        for t in (frames, out):
+            if t.dtype != torch.float32 or t.device != d.device or t.stride(2) != 1 or t.stride(1) != d.n_fft:
+                raise ValueError("frames and out must be float32 on the denoiser's device with contiguous (B, n_fft) hops")
+        H = frames.shape[0]
+        if check_weights:
+            self._bind()
+        ia_ptr, ia_stride, keep = None, 0, []
+        if init_angles is not None:
+            if init_angles.shape[0] != H:
+                raise ValueError("init_angles: one set of phases per hop of the group")
+            keep = [d._angles_ptr(init_angles[h], self.batch)[0] for h in range(H)]
+            packed = torch.stack(keep)                    # (H, B, 3, K, 2) float32, contiguous
+            keep = [packed]
+            ia_ptr, ia_stride = packed.data_ptr(), packed.stride(0)
+        with torch.cuda.device(d.device):
+            cur = torch.cuda.current_stream()
+            self.lib.check(self.lib.dn_pipe_submit_group(self.handle, frames.data_ptr(), frames.stride(0) if H > 1 else 0, hx.data_ptr(), out.data_ptr(),
+                                                         out.stride(0) if H > 1 else 0, ia_ptr, ia_stride, seed, stream_id0, H, d.n_iter, d.momentum,
+                                                         C.c_void_p(cur.cuda_stream)))
+            for k in keep:
+                if not torch.cuda.is_current_stream_capturing():
+                    k.record_stream(cur)
+
     def flush(self) -> None:
         with torch.cuda.device(self.dn.device):
             st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -306,6 +346,46 @@ class PipelinedStream(_Pipe):
         self.push_(hop, out, init_angles)
         hop.record_stream(torch.cuda.current_stream(self.dn.device))
         return out
+
+    def push_group_(self, hops: torch.Tensor, out: torch.Tensor, init_angles: torch.Tensor | None = None, check_weights: bool = True) -> None:
+        """Allocation-free push of a GROUP (``set_group(H)``): ``hops`` and ``out`` of shape ``(H, B, hop_length)`` (float32 or int16 PCM) -- H
+        consecutive hops of every stream in ONE launch (dn_pipe_stream_push_group), H hops emitted: the stream a one-hop pipe emits,
+        H - 1 hops later (zeros until then).  Capturable like ``push_``."""
+        d = self.dn
+        H = self.group
+        for t, name in ((hops, "hops"), (out, "out")):
+            if t.device != d.device or tuple(t.shape) != (H, self.batch, d.hop) or t.dtype not in (torch.float32, torch.int16) or t.stride(2) != 1 \
+                    or t.stride(1) != d.hop:
+                raise ValueError(f"{name} must be float32 or int16 of shape {(H, self.batch, d.hop)} on {d.device} with contiguous (B, hop) rows")
+        if check_weights:
+            self._bind()
+        ia_ptr, ia_stride, keep = None, 0, None
+        if init_angles is not None:
+            keep = torch.stack([d._angles_ptr(init_angles[h], self.batch)[0] for h in range(H)])
+            ia_ptr, ia_stride = keep.data_ptr(), keep.stride(0)
+        with torch.cuda.device(d.device):
+            cur = torch.cuda.current_stream()
+            self.lib.check(self.lib.dn_pipe_stream_push_group(self.handle, hops.data_ptr(), hops.stride(0), int(hops.dtype == torch.int16), out.data_ptr(),
+                                                              out.stride(0), int(out.dtype == torch.int16), ia_ptr, ia_stride, self.seed,
+                                                              self.stream_id0, d.n_iter, d.momentum, C.c_void_p(cur.cuda_stream)))
+            if keep is not None and not torch.cuda.is_current_stream_capturing():
+                keep.record_stream(cur)
+
+    def push_group(self, hops: torch.Tensor, init_angles: torch.Tensor | None = None) -> torch.Tensor:
+        out = torch.empty_like(hops)
+        self.push_group_(hops, out, init_angles)
+        hops.record_stream(torch.cuda.current_stream(self.dn.device))
+        return out
+
+    def flush_group(self, s16: bool = False):
+        """Drains a group pipe: ``(out (H, B, hop_length), valid)`` -- the pending frames' hops first, zero hops behind them."""
+        d = self.dn
+        out = torch.empty(self.group, self.batch, d.hop, dtype=torch.int16 if s16 else torch.float32, device=d.device)
+        valid = C.c_int32()
+        with torch.cuda.device(d.device):
+            st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+            self.lib.check(self.lib.dn_pipe_stream_flush_group(self.handle, out.data_ptr(), out.stride(0), int(s16), C.byref(valid), st))
+        return out, valid.value
 
     def graph_step(self, hop: torch.Tensor, out: torch.Tensor, init_angles: torch.Tensor | None = None) -> "torch.cuda.CUDAGraph":
         """Capture ONE push into a hipGraph (BASELINE config 5: the hipGraph-captured step).  Replaying it is a push of

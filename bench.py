@@ -123,6 +123,12 @@ def default_depth(batch, n_fft):
     return 4 if batch <= 384 else 2 if batch < 1024 else 1
 
 
+def default_group(batch, n_fft):
+    """Hops per launch (dn_pipe_set_group) for throughput: with about one stream per CU (up to 384 streams) a launch carries four consecutive hops
+    of every stream and the WHOLE Griffin-Lim chains of the previous four -- the occupancy of the depth-4 pipe without its parked chains."""
+    return 4 if n_fft == 1024 and batch <= 384 else 0
+
+
 def prewarm(step, seconds=0.3):
     """Untimed: bring the GPU out of its idle power state (a cold GPU runs the first hundreds of hops at roughly half clock)."""
     t_pre = time.perf_counter()
@@ -593,7 +599,9 @@ def main():
     ap.add_argument("--pipes", type=int, default=0, help="with --queues: the batch as this many pipes (default: one per queue), pipe i on queue i %% queues")
     ap.add_argument("--graph-hops", type=int, default=1, help="with --stream --graph: consecutive pushes captured per graph")
     ap.add_argument("--depth", type=int, default=0, help="hops of one stream in flight (dn_pipe_set_depth, 1..4); 0 = the throughput default for the batch "
-                                                            "(4 up to 384 streams, 2 below 768, else 1); 1 = output after the next hop")
+                                                            "(4 up to 384 streams, 2 below 1,024, else 1); 1 = output after the next hop.  Used when --group is 0")
+    ap.add_argument("--group", type=int, default=-1, help="hops of every stream per launch (dn_pipe_set_group, 0..4: whole Griffin-Lim chains, nothing parked "
+                                                            "between launches); -1 = the throughput default (4 up to 384 streams); 0 = one hop per launch (--depth)")
     ap.add_argument("--no-extras", action="store_true", help="skip the bounded side measurements carried in the line (config 3, config 5, R1, batch-1 latency)")
     args = ap.parse_args()
 
@@ -637,27 +645,41 @@ def main():
         return side_measurement(args, dn, B, dev)
     lo, hi = shard_range(B * world, world, rank)          # this rank's global stream ids
     g = torch.Generator().manual_seed(1234 + rank)
-    frames = (0.1 * torch.randn(B, N_FFT, generator=g)).to(dev if on_gpu else "cpu")
-    hx = dn.init_hx(B)
-    out = torch.empty_like(frames)
-
-    # Product configuration for throughput: software-pipelined hops (dn_pipe_*): ONE launch per hop whose workgroups are
-    # hop n's Griffin-Lim next to hop n+1's analysis + model + inverse mel; hx is the only inter-hop dependency.
-    depth = 1
+    # Product configuration for throughput (n_fft 1024, about one stream per CU): HOP GROUPS (dn_pipe_set_group): ONE launch carries `group`
+    # consecutive hops of every stream -- their front halves (analysis + model + inverse mel) in order, hx handed on inside the launch -- beside the
+    # WHOLE Griffin-Lim chains of the hops the previous launch fronted, one wavefront each.  A "step" stays what it was: one hop (256 frames per
+    # GPU); K steps are K / group launches.  --group 0: one launch per hop (the deep pipe of round 3, --depth).
+    depth, group = 1, 0
     if rehearsal:
         pipe = dn.pipe(B)
     else:
         from audio_denoising_amd.pipeline import HopPipeline
         pipe = None if args.serial else HopPipeline(dn, B)
         if pipe is not None:
-            depth = args.depth if args.depth > 0 else default_depth(B, N_FFT)
-            pipe.set_depth(depth)
+            group = args.group if args.group >= 0 else default_group(B, N_FFT)
+            if group > 0:
+                pipe.set_group(group)
+            else:
+                depth = args.depth if args.depth > 0 else default_depth(B, N_FFT)
+                pipe.set_depth(depth)
+    G = max(group, 1)
+    # every hop of a group is a different batch of 256 synthetic frames (a launch reads G x 256 frames)
+    frames = (0.1 * torch.randn(G, B, N_FFT, generator=g)).to(dev if on_gpu else "cpu")
+    hx = dn.init_hx(B)
+    out = torch.empty_like(frames)
 
-    def step(i):
+    def advance(n):
+        """n hops of work for every stream"""
         if pipe is None:
-            dn.process_frame_(frames, hx, out, seed=1000 + i, stream_id0=lo)
+            for i in range(n):
+                dn.process_frame_(frames[0], hx, out[0], seed=1000 + i, stream_id0=lo)
+        elif group > 0:
+            for j in range(0, n, group):
+                k = min(group, n - j)
+                pipe.submit_group(frames[:k], hx, out[:k], seed=1000, stream_id0=lo, check_weights=False)
         else:
-            pipe.submit(frames, hx, out, seed=1000, stream_id0=lo, check_weights=False)
+            for i in range(n):
+                pipe.submit(frames[0], hx, out[0], seed=1000, stream_id0=lo, check_weights=False)
 
     def sync():
         if on_gpu:
@@ -675,19 +697,17 @@ def main():
     # half clock: 124 us/step instead of 68), then the W warm-up steps of the contract
     t_pre = time.perf_counter()
     while on_gpu and time.perf_counter() - t_pre < 0.5:
-        for i in range(50):
-            step(i)
+        advance(48)
         sync()
-    # Throughput is a steady-state quantity: the pipe stays PRIMED across both boundaries of the timed region (its `depth` hops in flight are
-    # neither drained before t0 nor after the last step), so the K launches between the two barrier + synchronize brackets are K hops of work for
-    # every stream -- the front half of a new hop and one chain segment of each hop in flight -- and nothing else.  The drain is timed right after
-    # and reported beside it (`drain_ms`, `ms_per_step_with_drain`: what a finite job of K hops pays).
-    for i in range(max(args.warmup, 2 * depth)):
-        step(i)
+    # Throughput is a steady-state quantity: the pipe stays PRIMED across both boundaries of the timed region (the hops in flight -- one group, or
+    # `depth` hops -- are neither drained before t0 nor after the last step), so the launches between the two barrier + synchronize brackets are K
+    # hops of work for every stream -- K front halves and K whole chains -- and nothing else.  The drain is timed right after and reported beside
+    # it (`drain_ms`, `ms_per_step_with_drain`: what a finite job of K hops pays).
+    warm = max(args.warmup, 2 * max(depth, G))
+    advance(-(-warm // G) * G)
     fence(drain=False)
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
+    advance(args.steps)
     fence(drain=False)
     elapsed = time.perf_counter() - t0
     td = time.perf_counter()
@@ -727,8 +747,9 @@ def main():
             "ranks_seen": ranks_seen, "ingress": "local",
             "config": {"workload": "configs[1]: batch 256 synthetic 32 ms frames per GPU, n_fft=1024 hop=512 n_mels=80, GRUUNet2 fp32 "
                                    "(dari_tult weights, num_compressed_bins=5), 32-iter Griffin-Lim, device-RNG initial phases, hx carried; "
-                                   "every step re-processes the same 256 resident frames per GPU (the path is compute-bound: no data-dependent work)",
-                       "streams_per_gpu": B, "frames_per_step": B * world, "sample_rate": SR, "n_fft": N_FFT, "hop": HOP,
+                                   "a step = one hop of 256 resident synthetic frames per GPU (the hops of a group are different frames; the same buffers "
+                                   "are re-processed step after step: the path is compute-bound, no data-dependent work)",
+                       "streams_per_gpu": B, "hops_per_launch": G, "frames_per_step": B * world, "sample_rate": SR, "n_fft": N_FFT, "hop": HOP,
                        "n_mels": N_MELS, "griffinlim_iters": GL_ITERS, "conv_precision": args.conv,
                        "parallelism": f"stream-sharded x{world} (no data-path collective)"},
         }
@@ -739,75 +760,101 @@ def main():
                          "rank0_device": (torch.cuda.get_device_name(dev) if on_gpu else "cpu"), "local_rank": local}
     if rank == 0 and on_gpu:
         # the same K steps strictly one after another, nothing overlapped (dn_process_frame: one launch, no added hop of latency)
+        f0, o0 = frames[0], out[0]
         torch.cuda.synchronize()
         ts = time.perf_counter()
         for i in range(args.steps):
-            dn.process_frame_(frames, hx, out, seed=5000 + i, stream_id0=lo)
+            dn.process_frame_(f0, hx, o0, seed=5000 + i, stream_id0=lo)
         torch.cuda.synchronize()
         serial_ms = 1e3 * (time.perf_counter() - ts) / args.steps
-        kt = staged_kernel_times(dn, frames, hx, 200)
-        # the same workload through the one-hop pipe (output after the next submit): wavefront per column + head start
-        depth1_ms = time_pipe(dn, B, dev, max(args.steps, 200), 1)[1] if (depth != 1 or pipe is None) else ms
-        # dominant kernel of the timed region: hop_kernel.  Mean launch duration from HIP events recorded on the launch
-        # stream around a run of back-to-back launches (each launch = one whole hop of work for the batch).
-        if pipe is not None:
-            # (one event pair around a run of back-to-back launches: an event between every two launches adds ~4 us each)
-            n_ev = min(args.steps, 100)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            pipe.submit(frames, hx, out, seed=1, stream_id0=lo)
+        kt = staged_kernel_times(dn, f0, hx, 200)
+        # the same workload one hop per launch: the one-hop pipe (output after the next submit: wavefront per column + head start) and the deep pipe
+        # of round 3 (four hops of a stream in flight as chain segments parked between launches)
+        depth1_ms = time_pipe(dn, B, dev, max(args.steps, 200), 1)[1] if (group > 0 or depth != 1 or pipe is None) else ms
+        depth4_ms = time_pipe(dn, B, dev, max(args.steps, 200), default_depth(B, N_FFT))[1] if (group > 0 or pipe is None) else ms
+        # dominant kernel of the timed region.  Mean launch duration from HIP events recorded on the launch stream around a run of back-to-back
+        # launches (one event pair around the run: an event between every two launches adds ~4 us each).
+        n_ev = min(args.steps, 100)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        per_launch = 1
+        if pipe is not None and group > 0:
+            per_launch = group
+            n_ev = max(n_ev // group, 5)
+            pipe.submit_group(frames, hx, out, seed=1, stream_id0=lo)
             e0.record()
             for i in range(n_ev):
-                pipe.submit(frames, hx, out, seed=1, stream_id0=lo, check_weights=False)
+                pipe.submit_group(frames, hx, out, seed=1, stream_id0=lo, check_weights=False)
             e1.record()
             pipe.flush()
             torch.cuda.synchronize()
             dom_ms = e0.elapsed_time(e1) / n_ev
-            dom_name, dom_flop = ("hop_kernel (Griffin-Lim blocks of the hops in flight + this hop's analysis/model/inverse-mel blocks: "
-                                  "one launch = one hop of work for every stream)"), TOTAL_FLOP_PER_FRAME
+            dom_name = (f"group_kernel (one launch = {group} consecutive hops of work for every stream: the WHOLE Griffin-Lim chains of the {group} hops "
+                        f"the previous launch fronted, one wavefront each, + the analysis/model/inverse-mel blocks of {group} new hops, in order)")
+            dom_note = ("fp32-VALU bound (78 % of the flops are FFT butterflies on the fp32 vector ALU, the convs run on fp32 MFMA; vector and matrix "
+                        "fp32 peaks are both 157.3 TF, so one roof serves both); "
+                        f"algorithmic = 6.50 MFLOP per frame (198 rFFT-1024 x 25,600 + mel + convs + inverse mel) x 256 frames x {group} hops per launch")
+        elif pipe is not None:
+            pipe.submit(f0, hx, o0, seed=1, stream_id0=lo)
+            e0.record()
+            for i in range(n_ev):
+                pipe.submit(f0, hx, o0, seed=1, stream_id0=lo, check_weights=False)
+            e1.record()
+            pipe.flush()
+            torch.cuda.synchronize()
+            dom_ms = e0.elapsed_time(e1) / n_ev
+            dom_name = ("hop_kernel (Griffin-Lim blocks of the hops in flight + this hop's analysis/model/inverse-mel blocks: "
+                        "one launch = one hop of work for every stream)")
             dom_note = ("fp32-VALU bound (78 % of the flops are FFT butterflies on the fp32 vector ALU, the convs run on fp32 MFMA; vector and matrix "
                         "fp32 peaks are both 157.3 TF, so one roof serves both); "
                         "algorithmic = 6.50 MFLOP per frame (198 rFFT-1024 x 25,600 + mel + convs + inverse mel) x 256 frames per launch")
         else:
-            n_ev = min(args.steps, 100)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for i in range(n_ev):
-                dn.process_frame_(frames, hx, out, seed=1 + i, stream_id0=lo)
+                dn.process_frame_(f0, hx, o0, seed=1 + i, stream_id0=lo)
             e1.record()
             torch.cuda.synchronize()
             dom_ms = e0.elapsed_time(e1) / n_ev
-            dom_name, dom_flop = "frame_kernel (P1-P12 of one stream per workgroup, nothing overlapped)", TOTAL_FLOP_PER_FRAME
+            dom_name = "frame_kernel (P1-P12 of one stream per workgroup, nothing overlapped)"
             dom_note = "fp32-VALU bound; algorithmic = 6.50 MFLOP per frame x 256 frames per launch"
+        dom_flop = TOTAL_FLOP_PER_FRAME * per_launch
         gl_s = dom_ms * 1e-3
         ach = dom_flop * B / gl_s / 1e12
         traffic = None
         pmc = os.path.join(REPO, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
-            traffic = json.load(open(pmc)).get("hop_kernel_hbm_bytes_per_launch" if pipe is not None else "frame_kernel_hbm_bytes_per_launch")
+            traffic = json.load(open(pmc)).get("frame_kernel_hbm_bytes_per_launch" if pipe is None else
+                                               "group_kernel_hbm_bytes_per_launch" if group > 0 else "hop_kernel_hbm_bytes_per_launch")
         bf16 = args.conv == "bf16"
         conv_peak = PEAK_BF16_TFLOPS if bf16 else PEAK_FP32_TFLOPS
         conv_ach = CONV_FLOP_PER_FRAME * B / (kt["cell"] * 1e-3) / 1e12
         line.update({
-            "roofline": {"bound": "mfma", "bound_detail": "fp32-valu (FFT butterflies) + fp32 MFMA (convs): the fp32 compute roof, 157.3 TFLOP/s either way",
+            "roofline": {"bound": "fp32-valu", "bound_detail": "fp32 vector ALU (FFT butterflies, 78 % of the flops) + fp32 MFMA (convs): the fp32 compute roof, "
+                                                               "157.3 TFLOP/s either way; not HBM (hbm_frac) and not the matrix pipe",
                          "kernel": dom_name, "achieved": round(ach, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach / PEAK_FP32_TFLOPS, 4), "traffic": traffic, "note": dom_note,
-                         "launch_ms": round(dom_ms, 4),
-                         "hbm_frac": round(HBM_BYTES_PER_FRAME * B / gl_s / 1e9 / PEAK_HBM_GBS, 6)},
+                         "launch_ms": round(dom_ms, 4), "hops_per_launch": per_launch, "ms_per_hop": round(dom_ms / per_launch, 4),
+                         "algorithmic_bytes_per_launch": HBM_BYTES_PER_FRAME * B * per_launch,
+                         "hbm_frac": round(HBM_BYTES_PER_FRAME * B * per_launch / gl_s / 1e9 / PEAK_HBM_GBS, 6)},
             "kernel_ms": {k: round(v, 4) for k, v in kt.items()},
             # MFMA utilisation of the UNet convs: conv FLOPs / (stand-alone cell kernel time x MFMA peak of the conv dtype)
             "conv_mfma": {"kernel": "cell_kernel_bf16 (v_mfma_f32_16x16x32_bf16)" if bf16 else "cell_kernel (fp32 v_mfma_f32_16x16x4_f32)",
                           "achieved": round(conv_ach, 3), "peak": conv_peak, "unit": "TFLOP/s", "frac": round(conv_ach / conv_peak, 5),
                           "note": "0.24 GFLOP per batch-256 launch is 1.5 us at the fp32 peak: structurally latency-bound (SURVEY section 7)"},
             "schedule": "unpipelined, 1 launch per hop (dn_process_frame), no added latency" if pipe is None
+                        else f"hop groups (dn_pipe_submit_group): 1 launch per {group} consecutive hops of every stream; their front halves run in order inside "
+                             f"the launch beside the whole Griffin-Lim chains of the previous {group} hops (one wavefront each, never parked: bit-identical "
+                             f"to the one-hop pipe); input arrives {group} hops at a time, the output of a group is complete one launch later" if group > 0
                         else f"software-pipelined, 1 launch per hop (dn_pipe_submit), depth {depth}: {depth} hops of every stream in flight, "
                              f"output complete {depth} launch(es) after its submit" + ("" if depth == 1 else
                              "; the Griffin-Lim chain of a frame runs as one segment per launch, one wavefront per stream and segment (bit-identical to depth 1)"),
             "pipeline_depth": depth if pipe is not None else 0,
-            "timed_region": "steady state: K launches between barrier + synchronize brackets, the pipe primed on both sides (each launch = one hop of "
-                            "work for every stream: a new hop's front half + one chain segment of each hop in flight); the drain is timed separately",
+            "hops_per_launch": G,
+            "timed_region": "steady state: K hops of work for every stream between barrier + synchronize brackets, the pipe primed on both sides (K front "
+                            "halves and K whole Griffin-Lim chains" + (f" in K / {group} launches" if group > 0 else "") + "); the drain is timed separately",
             "drain_ms": round(1e3 * drain_s, 4),
             "ms_per_step_with_drain": round(1e3 * (elapsed + drain_s) / args.steps, 4),
             "depth1_ms_per_step": round(depth1_ms, 4),
+            "depth4_ms_per_step": round(depth4_ms, 4),
             "serial_ms_per_step": round(serial_ms, 4),
             "whole_path": {"tflops": round(TOTAL_FLOP_PER_FRAME * value / 1e12, 3),
                            "fp32_frac": round(TOTAL_FLOP_PER_FRAME * value / 1e12 / (PEAK_FP32_TFLOPS * world), 4),

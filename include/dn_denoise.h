@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define DN_ABI_VERSION 3
+#define DN_ABI_VERSION 4
 
 typedef enum dn_status {
     DN_OK = 0,
@@ -271,6 +271,29 @@ int dn_pipe_set_head_start(dn_pipe* p, int32_t iterations);
  * Call while nothing is in flight (after create or flush); synchronises the device. */
 #define DN_PIPE_MAX_DEPTH 4
 int dn_pipe_set_depth(dn_pipe* p, int32_t depth);
+/* Hop groups (n_fft 1024; DN_ERR_UNSUPPORTED at 1536): the loop body of app3.py:178-226 for `hops` CONSECUTIVE hops of every stream in ONE launch.
+ * A deep pipe (above) pays for every launch boundary inside a Griffin-Lim chain: the chain parks in HBM and comes back at the head of the next
+ * launch.  With dn_pipe_set_group(p, H), 1 <= H <= DN_PIPE_MAX_GROUP, a launch is as long as a chain instead: dn_pipe_submit_group carries up to H
+ * new hops of every stream -- hop h of the group reads frames + h * frames_stride, its front half (P1-P10) runs behind hop h-1's with hx handed on,
+ * its result goes to out + h * out_stride, its injected phases (parity mode) come from init_angles + h * init_stride (strides in floats) -- beside
+ * the WHOLE chains of the hops the previous launch fronted, one wavefront each.  Nothing is parked between launches; frames, hx and samples are
+ * those of the one-hop pipe bit for bit (same seeds: the f-th frame of the pipe draws from seed + f).  The output of a group is complete after
+ * the next dn_pipe_submit_group or one dn_pipe_flush.  Throughput of the deep pipe without its hand-off, for input that arrives H hops at a time.
+ * Streaming form: dn_pipe_stream_push_group takes exactly H hops (hop_in + h * in_stride, elements of the input type) and emits H hops
+ * (hop_out + i * out_stride); the emitted stream is the one-hop pipe's delayed by H - 1 more hops (zeros until then), and
+ * dn_pipe_stream_flush_group emits the frames still pending first and zero hops behind them (always H hops; *hops_valid, may be NULL, says how
+ * many carry samples as far as this host thread's own pushes tell -- after graph replays ask dn_pipe_get_counters for `pending` before the flush).
+ * dn_pipe_set_group: call while nothing is in flight; H = 0 returns the pipe to single hops; synchronises the device; excludes depth > 1, a head
+ * start and the host-buffer transport.  dn_pipe_submit on a group pipe is a group of one hop. */
+#define DN_PIPE_MAX_GROUP 4
+int dn_pipe_set_group(dn_pipe* p, int32_t hops);
+int dn_pipe_submit_group(dn_pipe* p, const float* frames, int64_t frames_stride, float* hx, float* out, int64_t out_stride,
+                         const float* init_angles, int64_t init_stride, uint64_t seed, uint64_t stream_id0, int32_t hops,
+                         int32_t n_iter, float momentum, void* stream);
+int dn_pipe_stream_push_group(dn_pipe* p, const void* hop_in, int64_t in_stride, int32_t in_is_s16, void* hop_out, int64_t out_stride,
+                              int32_t out_is_s16, const float* init_angles, int64_t init_stride, uint64_t seed, uint64_t stream_id0,
+                              int32_t n_iter, float momentum, void* stream);
+int dn_pipe_stream_flush_group(dn_pipe* p, void* hop_out, int64_t out_stride, int32_t out_is_s16, int32_t* hops_valid, void* stream);
 /* How the pending hop's Griffin-Lim is laid out on the GPU (n_fft 1024; results are bit-identical either way):
  *   DN_GL_WAVE_PER_COLUMN  three wavefronts per stream, one per STFT column: the shortest chain for one stream -- right when there is
  *                          about one stream per CU (the batch-256 metric);

@@ -81,6 +81,9 @@ inline hipError_t hipHostFree(void* p) { free(p); return 0; }
 inline void __threadfence_system() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 #define __HIP_MEMORY_SCOPE_SYSTEM 5
 template <typename T> inline void __hip_atomic_store(T* p, T v, int, int) { __atomic_store_n(p, v, __ATOMIC_SEQ_CST); }
+template <typename T> inline T __hip_atomic_fetch_add(T* p, T v, int, int) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+#define DN_WAIT_VMEM() ((void)0)
+#define DN_OPAQUE_ZERO(z) ((z) = 0)
 inline const char* hipGetErrorString(hipError_t) { return "emulated"; }
 
 namespace dn_emu {

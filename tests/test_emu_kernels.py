@@ -602,6 +602,93 @@ def test_deep_pipe_runs_the_chain_in_segments_bit_identically(lib, dsp, depth):
         assert np.array_equal(x, y)
 
 
+def _run_groups(lib, dsp, m, B, n_hops, g, H, sizes=None, stream=False, s16=False, init=None, n_iter=4):
+    """the same hops as _run_pipe, submitted as groups (dn_pipe_set_group): `sizes` = hops per submit (frame mode; default H each)"""
+    pipe = C.c_void_p()
+    create = lib.dn_pipe_stream_create if stream else lib.dn_pipe_create
+    lib.check(create(m, dsp, B, 0, C.byref(pipe)))
+    lib.check(lib.dn_pipe_set_group(pipe, H))
+    outs = []
+    if not stream:
+        hx = np.zeros((B, 17, 5), np.float32)
+        frames = emu.f32(np.stack([g["signal"][:B, h * P.hop: h * P.hop + P.n_fft] for h in range(n_hops)]))
+        out = np.zeros((n_hops, B, P.n_fft), np.float32)
+        ia = None if init is None else emu.f32(np.stack(init))
+        h = 0
+        for k in (sizes or [H] * ((n_hops + H - 1) // H)):
+            k = min(k, n_hops - h)
+            if k == 0:
+                break
+            lib.check(lib.dn_pipe_submit_group(pipe, emu.ptr(frames[h:]), B * P.n_fft, emu.ptr(hx), emu.ptr(out[h:]), B * P.n_fft,
+                                               None if ia is None else emu.ptr(ia[h:]), 0 if ia is None else ia[0].size, 11, 3, k, n_iter, 0.99, None))
+            h += k
+        assert h == n_hops
+        lib.check(lib.dn_pipe_flush(pipe, n_iter, 0.99, None))
+        outs = [out[i] for i in range(n_hops)] + [hx]
+    else:
+        dt = np.int16 if s16 else np.float32
+        assert (n_hops + 1) % H == 0
+        for h0 in range(0, n_hops + 1, H):
+            x = np.stack([g["signal"][:B, h * P.hop:(h + 1) * P.hop] for h in range(h0, h0 + H)])
+            hop_in = np.ascontiguousarray(np.clip(x * 32767.0, -32767, 32767).astype(np.int16)) if s16 else emu.f32(x)
+            o = np.zeros((H, B, P.hop), dt)
+            lib.check(lib.dn_pipe_stream_push_group(pipe, emu.ptr(hop_in), B * P.hop, int(s16), emu.ptr(o), B * P.hop, int(s16), None, 0, 11, 3, n_iter, 0.99, None))
+            outs += [o[i] for i in range(H)]
+        o = np.zeros((H, B, P.hop), dt)
+        valid = C.c_int32(-1)
+        lib.check(lib.dn_pipe_stream_flush_group(pipe, emu.ptr(o), B * P.hop, int(s16), C.byref(valid), None))
+        outs += [o[i] for i in range(H)]
+        ring, ola, hx = np.zeros((B, P.n_fft), np.float32), np.zeros((B, P.n_fft), np.float32), np.zeros((B, 17, 5), np.float32)
+        lib.check(lib.dn_pipe_stream_get_state(pipe, emu.ptr(ring), emu.ptr(ola), emu.ptr(hx), None))
+        outs += [valid.value, ring, ola, hx]
+    lib.dn_pipe_destroy(pipe)
+    return outs
+
+
+@pytest.mark.parametrize("H", [2, 4])
+def test_hop_groups_run_whole_chains_bit_identically(lib, dsp, H):
+    """dn_pipe_set_group: a launch carries H consecutive hops of every stream (front halves in order, hx handed on) beside the WHOLE Griffin-Lim
+    chains of the previous group, one wavefront each -- nothing is parked.  Frames and hx must equal the one-hop pipe's bit for bit (device-RNG
+    and injected phases; full groups, a short last group, uneven submits, a single-hop submit through dn_pipe_submit's route)."""
+    from audio_denoising_amd._lib import DN_GL_WAVE_PER_COLUMN
+    g = {"signal": load_golden("stream_S.npz")["signal"]}
+    B, n_hops = 2, 5
+    m = make_model(lib, 5)
+    rg = np.random.default_rng(23)
+    init = [emu.f32(rg.random((B, 3, P.n_stft, 2))) for _ in range(n_hops)]
+    for kw in (dict(init=None), dict(init=init)):
+        a = _run_pipe(lib, dsp, m, DN_GL_WAVE_PER_COLUMN, B, n_hops, g, n_iter=4, **kw)
+        for sizes in (None, [1, H, 1, H]):
+            b = _run_groups(lib, dsp, m, B, n_hops, g, H, sizes=sizes, n_iter=4, **kw)
+            assert len(a) == len(b)
+            for x, y in zip(a, b):
+                assert np.array_equal(x, y)
+        assert np.abs(a[0]).max() > 0
+    lib.dn_model_destroy(m)
+
+
+@pytest.mark.parametrize("s16", [False, True])
+def test_streaming_hop_groups_emit_the_one_hop_pipes_samples_later(lib, dsp, s16):
+    """dn_pipe_stream_push_group: H hops in, H hops out per launch; the chains of one stream finish in the same launch and fold into its
+    overlap-add line IN ORDER.  The emitted stream is the one-hop pipe's, H - 1 hops later (zeros first); ring, overlap-add line and hx after the
+    drain are the same."""
+    from audio_denoising_amd._lib import DN_GL_WAVE_PER_COLUMN
+    g = {"signal": load_golden("stream_S.npz")["signal"]}
+    H, B, n_hops = 3, 2, 5          # 6 pushes = two groups of three
+    m = make_model(lib, 5)
+    a = _run_pipe(lib, dsp, m, DN_GL_WAVE_PER_COLUMN, B, n_hops, g, stream=True, s16=s16, n_iter=3)
+    b = _run_groups(lib, dsp, m, B, n_hops, g, H, stream=True, s16=s16, n_iter=3)
+    lib.dn_model_destroy(m)
+    ea = np.concatenate(a[:-3], axis=1)                      # n_hops + 1 pushes and one flush
+    eb = np.concatenate(b[:-4], axis=1)                      # two groups and one flush group
+    lag = (H - 1) * P.hop
+    assert np.array_equal(eb[:, lag:lag + ea.shape[1]], ea) and not eb[:, :lag].any() and np.abs(ea).max() > 0
+    assert not eb[:, lag + ea.shape[1]:].any()               # zero hops behind the drained frames
+    assert b[-4] == H                                        # frames 2, 3, 4 were pending: three hops of the flush carry samples
+    for x, y in zip(a[-3:], b[-3:]):
+        assert np.array_equal(x, y)
+
+
 def test_device_rng_is_philox4x32_10_and_matches_the_published_known_answers(lib, dsp):
     """Integer work, bit-exact: the device generator behind rand_init=True (app3.py:149-153) against an independent numpy restatement of
     Philox4x32-10 that is itself pinned by the three known-answer vectors Random123 publishes; the first of them is reachable through the

@@ -1176,6 +1176,172 @@ def test_pipelined_hop_at_batch_256_directly_against_the_oracle(dev, depth):
     assert (hx.cpu() - h).abs().max().item() <= GUARD_HX
 
 
+@pytest.mark.parametrize("H", [2, 4])
+def test_hop_groups_are_bit_identical_to_the_one_hop_pipe_at_batch_256(dev, H):
+    """dn_pipe_set_group (the headline's schedule since round 4): a launch carries H consecutive hops of every stream -- their front halves in
+    order, hx handed on inside the launch -- beside the WHOLE Griffin-Lim chains of the previous group, one wavefront each; nothing is parked
+    between launches.  Nine chained hops at batch 256 (full groups and a short last one), device-RNG phases, then injected phases with uneven
+    submits and a drain in mid-sequence: frames and hx equal the depth-1 pipe (a wavefront per column + head start) bit for bit.  Streaming: the
+    same int16 samples H - 1 pushes later, the same overlap-add lines, rings and hx.  Also 32 > n_iter in {0, 1}."""
+    from audio_denoising_amd.pipeline import Denoiser, HopPipeline, PipelinedStream
+    p = _params("S")
+    B, n = 256, 9
+    dn = Denoiser(_model(dev, 5), p.sample_rate, p.n_fft, p.hop, p.n_mels)
+    g = torch.Generator().manual_seed(900 + H)
+    frames = (0.1 * torch.randn(n, B, p.n_fft, generator=g)).to(dev)
+    inits = torch.rand(n, B, p.n_stft, 3, dtype=torch.complex64, generator=g).to(dev)
+    for variant in ("rng", "init+uneven+drain"):
+        ia = inits if variant != "rng" else None
+        pipe = HopPipeline(dn, B)
+        hx_a = dn.init_hx(B)
+        out_a = torch.empty_like(frames)
+        for i in range(n):
+            pipe.submit(frames[i], hx_a, out_a[i], seed=77, stream_id0=5, init_angles=None if ia is None else ia[i])
+        pipe.flush()
+        grp = HopPipeline(dn, B)
+        grp.set_group(H)
+        hx_b = dn.init_hx(B)
+        out_b = torch.empty_like(frames)
+        sizes = [H] * ((n + H - 1) // H) if variant == "rng" else [1, H, 1, H, H, H]
+        i = 0
+        for k in sizes:
+            k = min(k, n - i)
+            if k == 0:
+                break
+            grp.submit_group(frames[i:i + k], hx_b, out_b[i:i + k], seed=77, stream_id0=5, init_angles=None if ia is None else ia[i:i + k])
+            i += k
+            if variant != "rng" and i == 1 + H:
+                grp.flush()
+        grp.flush()
+        torch.cuda.synchronize()
+        assert grp.counters()[1] == n and grp.counters()[2] is False
+        assert torch.equal(hx_a, hx_b) and torch.equal(out_a, out_b) and torch.isfinite(out_a).all() and out_a.abs().max().item() > 0
+    for n_iter in (0, 1):
+        dn_few = Denoiser(_model(dev, 5), p.sample_rate, p.n_fft, p.hop, p.n_mels, n_iter=n_iter)
+        few = []
+        for grouped in (False, True):
+            pipe = HopPipeline(dn_few, 8)
+            hx = dn_few.init_hx(8)
+            f8 = frames[:H + 1, :8].contiguous()
+            outs = torch.empty_like(f8)
+            if grouped:
+                pipe.set_group(H)
+                pipe.submit_group(f8[:H], hx, outs[:H], seed=4)
+                pipe.submit_group(f8[H:], hx, outs[H:], seed=4)
+            else:
+                for i in range(H + 1):
+                    pipe.submit(f8[i], hx, outs[i], seed=4)
+            pipe.flush()
+            torch.cuda.synchronize()
+            few.append(outs)
+        assert torch.equal(few[0], few[1]) and torch.isfinite(few[0]).all() and few[0].abs().max().item() > 0
+    n_push = 3 * H
+    sig = (0.3 * torch.randn(8, n_push * p.hop, generator=g)).clamp(-1, 1)
+    pcm = (sig * 32767.0).to(torch.int16).to(dev)
+    ps = PipelinedStream(dn, 8, seed=3, stream_id0=40)
+    o = [ps.push(pcm[:, i * p.hop:(i + 1) * p.hop].contiguous()) for i in range(n_push)] + [ps.flush(s16=True)]
+    ring_a, ola_a, hx_a, frames_a = ps.state()
+    ea = torch.cat(o, 1)
+    pg = PipelinedStream(dn, 8, seed=3, stream_id0=40)
+    pg.set_group(H)
+    o = []
+    for i in range(0, n_push, H):
+        hops = torch.stack([pcm[:, j * p.hop:(j + 1) * p.hop] for j in range(i, i + H)]).contiguous()
+        o += list(pg.push_group(hops))
+    tail, valid = pg.flush_group(s16=True)
+    o += list(tail)
+    ring_b, ola_b, hx_b, frames_b = pg.state()
+    torch.cuda.synchronize()
+    eb = torch.cat(o, 1)
+    lag = (H - 1) * p.hop
+    assert valid == H and frames_a == frames_b == n_push - 1
+    assert torch.equal(eb[:, lag:lag + ea.shape[1]], ea) and not eb[:, :lag].any() and ea.abs().max().item() > 0
+    assert torch.equal(ring_a, ring_b) and torch.equal(ola_a, ola_b) and torch.equal(hx_a, hx_b)
+
+
+def test_hop_groups_at_batch_256_directly_against_the_oracle(dev):
+    """The configuration the bench times since round 4 (groups of four hops, whole chains), compared with the oracle DIRECTLY: batch 256, two
+    groups (eight chained hops) with injected Griffin-Lim phases, every stream: waveform at the batch-256 guard bands and the carried hx."""
+    from audio_denoising_amd.pipeline import Denoiser, HopPipeline
+    from oracle import dsp_ref, pipeline_ref
+    p = pipeline_ref.PARAMS_S
+    dn = Denoiser(_model(dev, 5), p.sample_rate, p.n_fft, p.hop, p.n_mels)
+    g = torch.Generator().manual_seed(2025)
+    n = 5
+    hops = 0.1 * torch.randn(n, 256, p.n_fft, generator=g)
+    inits = torch.rand(n, 256, p.n_stft, 3, dtype=torch.complex64, generator=g)
+    pipe = HopPipeline(dn, 256)
+    pipe.set_group(4)
+    hx = dn.init_hx(256)
+    fd, out = hops.to(dev), torch.empty(n, 256, p.n_fft, device=dev)
+    pipe.submit_group(fd[:4], hx, out[:4], seed=0, init_angles=inits[:4].to(dev))
+    pipe.submit_group(fd[4:], hx, out[4:], seed=0, init_angles=inits[4:].to(dev))
+    pipe.flush()
+    torch.cuda.synchronize()
+    fb = dsp_ref.melscale_fbanks(p.n_stft, p.n_mels, p.sample_rate)
+    sd = _state_dict("dari_tult")
+    h = torch.zeros(256, 17, 5)
+    with torch.no_grad():
+        for i in range(n):
+            ref = pipeline_ref.process_frame(sd, hops[i], h, p, fb, init_angles=inits[i])
+            h = ref["hx"]
+            rms, mx = _wave_close(out[i].cpu().numpy(), ref["out"].numpy())
+            per_stream = (out[i].cpu() - ref["out"]).pow(2).mean(dim=1).sqrt().numpy()
+            assert rms <= GUARD_B256_WAVE_RMS and mx <= GUARD_B256_WAVE_MAX and np.median(per_stream) <= GUARD_B256_STREAM_MEDIAN_RMS, (i, rms, mx)
+    assert (hx.cpu() - h).abs().max().item() <= GUARD_HX
+
+
+def test_hop_groups_refuse_what_they_do_not_run_and_replay_under_a_graph(dev):
+    """Errors of the group API (n_fft 1536, depth > 1, more hops than the group holds, overlapping outputs, single-hop stream calls on a group pipe),
+    and one captured dn_pipe_stream_push_group replayed: the control block advances on the device, so replays equal eager pushes bit for bit."""
+    from audio_denoising_amd._lib import DnError
+    from audio_denoising_amd.pipeline import Denoiser, HopPipeline, PipelinedStream
+    p, r1 = _params("S"), _params("R1")
+    dn = Denoiser(_model(dev, 5), p.sample_rate, p.n_fft, p.hop, p.n_mels)
+    with pytest.raises(DnError, match="1024"):
+        HopPipeline(Denoiser(_model(dev, 4), r1.sample_rate, r1.n_fft, r1.hop, r1.n_mels), 4).set_group(2)
+    pipe = HopPipeline(dn, 4)
+    pipe.set_depth(2)
+    with pytest.raises(DnError, match="deeper"):
+        pipe.set_group(2)
+    pipe.set_depth(1)
+    pipe.set_group(2)
+    with pytest.raises(DnError, match="group pipe"):
+        pipe.set_depth(2)
+    f = torch.zeros(3, 4, p.n_fft, device=dev)
+    with pytest.raises(DnError, match="hops must be"):
+        pipe.submit_group(f, dn.init_hx(4), torch.empty_like(f))
+    with pytest.raises(DnError, match="overlap"):
+        pipe.lib.check(pipe.lib.dn_pipe_submit_group(pipe.handle, f.data_ptr(), 0, dn.init_hx(4).data_ptr(), f.data_ptr(), 0, None, 0, 0, 0, 2, 32, 0.99, None))
+    ps = PipelinedStream(dn, 4)
+    ps.set_group(2)
+    with pytest.raises(DnError, match="groups of hops"):
+        ps.push(torch.zeros(4, p.hop, device=dev))
+    # replay
+    g = torch.Generator().manual_seed(31)
+    sig = (0.2 * torch.randn(64, 12 * p.hop, generator=g)).to(dev)
+    groups = [torch.stack([sig[:, (2 * k + j) * p.hop:(2 * k + j + 1) * p.hop] for j in range(2)]).contiguous() for k in range(6)]
+    eager = PipelinedStream(dn, 64, seed=9)
+    eager.set_group(2)
+    ref = [eager.push_group(x) for x in groups]
+    rep = PipelinedStream(dn, 64, seed=9)
+    rep.set_group(2)
+    hop_buf, out_buf = torch.empty_like(groups[0]), torch.empty_like(groups[0])
+    rep._bind()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        rep.push_group_(hop_buf, out_buf, check_weights=False)
+    got = []
+    for x in groups:
+        hop_buf.copy_(x)
+        graph.replay()
+        got.append(out_buf.clone())
+    torch.cuda.synchronize()
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
+    assert torch.stack(ref).abs().max().item() > 0
+
+
 @pytest.mark.parametrize("short,F", [("dari_tult", 64), ("dari_tult", 80), ("dari_tult2", 64)])
 def test_checkpoint_in_the_reference_format_loads_and_runs_on_the_gpu(dev, tmp_path, short, F):
     """SURVEY 8(f)-3 on the GPU tier: a `.pth` written with torch.save in the reference's own layout (app.py:75-91: config,
