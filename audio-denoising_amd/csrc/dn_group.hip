@@ -14,6 +14,19 @@ namespace dn {
 //   blocks [back_B, back_B + B)  P1-P10 of stream b's `group_hops` new hops, in order, into slots slot_next, slot_next + 1, ...
 // Same arithmetic, same seeds (seed + frame index, stream id), same slots as the one-hop pipe: frames, hx and emitted hops are bit-identical to it.
 // The price is granularity, not latency: input arrives H hops at a time and a frame is complete one launch (H hops) after its group was submitted.
+#ifdef DN_PROBE
+// diagnostic build only (tools/group_probe.py): the phases of front workgroup 0 for every hop of the group, start / end of every workgroup
+static __device__ unsigned long long g_group_front[DN_PIPE_MAX_GROUP][4];
+static __device__ unsigned long long g_group_wg[2048][2];
+#define DN_GSTAMP(h, id) do { if (tid == 0 && (int)blockIdx.x == a.back_blocks) { unsigned long long t_; \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); g_group_front[h][id] = t_; } } while (0)
+#define DN_GWG(id) do { if (tid == 0 && blockIdx.x < 2048) { unsigned long long t_; \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); g_group_wg[blockIdx.x][id] = t_; } } while (0)
+#else
+#define DN_GSTAMP(h, id) do { } while (0)
+#define DN_GWG(id) do { } while (0)
+#endif
+
 template <int NFFT, bool STREAM, bool BF16, int CT>
 __global__ __launch_bounds__(kHopPipeThreads, 2) void group_kernel(DspDev d, CellDev cd, HopArgs a) {
     static_assert(NFFT == 1024, "whole chains run one wavefront per stream (dn_glw_body.hpp): n_fft 1024");
@@ -31,9 +44,11 @@ __global__ __launch_bounds__(kHopPipeThreads, 2) void group_kernel(DspDev d, Cel
         prime_hops = left <= 0 ? 0 : left < (long long)a.group_hops ? (int)left : a.group_hops;
     }
     const int fronted = a.front_B > 0 ? a.group_hops - prime_hops : 0;
+    DN_GWG(0);
     if ((int)blockIdx.x < a.back_blocks) {
         const size_t b = blockIdx.x;
         const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+        DN_WSTAMP(0);
         const bool runs = wv < (int)pending;
         if (pending && !runs) {            // (the workgroup's window tables: every wave fills its share; a wave with a chain does it inside glw_body)
             glw_fill_tables<NFFT, kHopPipeThreads>(smem, d, tid);
@@ -51,6 +66,7 @@ __global__ __launch_bounds__(kHopPipeThreads, 2) void group_kernel(DspDev d, Cel
             float* gl_out = reinterpret_cast<float*>((uint64_t)meta[8] | ((uint64_t)meta[9] << 32));
             glw_body<NFFT, STREAM ? kEmitStage : kEmitFrame>(smem, d, slot + sl.lin, init, seed, sid0, slot + sl.peak, gl_out, n_iter, mom, b, lane, wv,
                                                              nullptr, nullptr, 0, 0, -1, kGlwFresh, nullptr, tid);
+            DN_WSTAMP(7);
         }
         if (STREAM) {
             // P12 for the frames of this stream in order: hop_out <- ola[:hop]; ola <- concat(ola[hop:], 0) + frame * peak (app3.py:217-224).  The chains
@@ -107,11 +123,15 @@ __global__ __launch_bounds__(kHopPipeThreads, 2) void group_kernel(DspDev d, Cel
             int s = (int)slot_next + q;
             if (s >= a.n_slots) s -= a.n_slots;
             float* slot = a.slots + (size_t)s * a.slot_stride;
+            DN_GSTAMP(q, 0);
             stft_body<NFFT, false, true, kHopPipeThreads>(smem, dz, frames_in, nullptr, slot, slot + sl.peak, DN_PEAK_NORMALIZE | DN_PRE_WINDOW, b, tidz);   // P1-P6
             __syncthreads();
+            DN_GSTAMP(q, 1);
             cell_body<kHopPipeThreads / 64, BF16, CT>(smem, cz, slot, a.hx + z, slot + sl.diff, a.hx + z, 3, a.C, b, tidz);                               // P7
             __syncthreads();
+            DN_GSTAMP(q, 2);
             invmel_body<NFFT, true, kHopPipeThreads>(smem, dz, slot, slot + sl.diff, slot + sl.lin, 3 * a.B, b * 3, tidz);                              // P8-P10
+            DN_GSTAMP(q, 3);
             if (tid == 0) {
                 uint32_t* meta = reinterpret_cast<uint32_t*>(slot + sl.meta) + kSlotMeta * b;
                 const uint64_t seed = a.seed + frames + (unsigned long long)q;
@@ -137,6 +157,7 @@ __global__ __launch_bounds__(kHopPipeThreads, 2) void group_kernel(DspDev d, Cel
     }
     // ---- ticket: the last workgroup of the launch advances the control block (every workgroup has read it by then)
     __syncthreads();
+    DN_GWG(1);
     if (tid == 0) {
         const unsigned int t = atomicAdd(&a.ctl->done, 1u);
         if (t == gridDim.x - 1) {
@@ -171,3 +192,15 @@ void launch_group(const DspDev& d, const CellDev& c, const HopArgs& a, bool bf16
 }
 
 }  // namespace dn
+
+#ifdef DN_PROBE
+extern "C" int dn_probe_read_group_glw(unsigned long long* host32) {
+    return (int)hipMemcpyFromSymbol(host32, HIP_SYMBOL(dn::g_glw_probe), sizeof(dn::g_glw_probe));
+}
+extern "C" int dn_probe_read_group_front(unsigned long long* host16) {
+    return (int)hipMemcpyFromSymbol(host16, HIP_SYMBOL(dn::g_group_front), sizeof(dn::g_group_front));
+}
+extern "C" int dn_probe_read_group_wg(unsigned long long* host4096) {
+    return (int)hipMemcpyFromSymbol(host4096, HIP_SYMBOL(dn::g_group_wg), sizeof(dn::g_group_wg));
+}
+#endif

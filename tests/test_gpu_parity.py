@@ -46,6 +46,35 @@ def _wave_close(got, ref, scale=1.0):
     rms, mx = float(np.sqrt(np.mean(err ** 2))), float(np.abs(err).max())
     assert rms <= TOL_WAVE_RMS * scale and mx <= TOL_WAVE_MAX * scale, (rms, mx)
     return rms, mx
+
+
+def _f64_frames(hops, inits, p, short="dari_tult", hx0=None, n_iter=32):
+    """Float64 yardstick for a chain of hops (oracle/pipeline_np64.py: float64 numpy DSP on the fp32 window / filterbank constants, the model stage
+    = oracle/model_ref.forward on float64 weights, which oracle/make_f64_golden.py checks against the reference's own class in double to 1e-12).
+    hops: list of (B, n_fft) fp32 tensors, inits: list of (B, K, 3) complex64 -> (list of float64 waveforms, float64 hx)."""
+    from oracle import dsp_ref, model_ref, pipeline_np64
+    sd64 = {k: v.double() for k, v in _state_dict(short).items()}
+
+    def model64(x, hx):
+        with torch.no_grad():
+            o, h = model_ref.forward(sd64, torch.from_numpy(x), torch.from_numpy(hx))
+        return o.numpy(), h.numpy()
+    fb = dsp_ref.melscale_fbanks(p.n_stft, p.n_mels, p.sample_rate).numpy()
+    window = torch.hann_window(p.n_fft).numpy()
+    B = hops[0].shape[0]
+    hx = np.zeros((B, 17, p.num_compressed_bins)) if hx0 is None else hx0
+    outs = []
+    for f, ia in zip(hops, inits):
+        r = pipeline_np64.process_frame64(f.numpy(), hx, model64, window, fb, ia.numpy(), p.n_fft, p.hop, n_iter=n_iter)
+        hx = r["hx"]
+        outs.append(r["out"])
+    return outs, hx
+
+
+# Random frames against the float64 yardstick: the batch-256 guard bands (profiles/r04_parity_margins.txt: the GPU's own error has the same heavy tail
+# as the CPU oracle's -- it is the Griffin-Lim chain's amplification of ANY fp32 rounding -- so float64 does not allow tighter bands than these)
+GUARD_F64_WAVE_RMS = GUARD_B256_WAVE_RMS
+GUARD_F64_WAVE_MAX = GUARD_B256_WAVE_MAX
 CFG = dict(in_size=1, hidden_sizes=(17, 17, 17, 17), kernel_sizes=(3, 3, 3, 3), strides=(2, 2, 2, 2), paddings=(1, 1, 1, 1), num_gaussians=6)
 
 
@@ -326,6 +355,63 @@ def test_process_frame_full_batch_vs_oracle_sample_and_shard_invariance(dev):
     assert torch.isfinite(whole).all()
 
 
+def test_batch_256_waveform_error_is_attributed_against_float64(dev):
+    """Which side of the batch-256 comparison carries its long tail?  GPU and fp32 CPU oracle differ by up to 1.4e-3 on the worst of the 256
+    metric frames (signal RMS 8.9e-3) because 32 Griffin-Lim iterations amplify rounding by a frame-dependent factor.  Here both are measured
+    against the SAME algorithm in float64 (tests/golden/metric_f64_B256.npz: oracle/pipeline_np64.py with the model stage run by the
+    reference's own class in double, oracle/make_f64_golden.py): per stream the GPU must be as close to the float64 result as the reference's
+    own fp32 arithmetic is -- |gpu - f64| <= 2 |cpu_fp32 - f64| + a small floor, on the waveform (RMS and max-abs) and on the mel residual --
+    and over the batch the GPU's error distribution must not sit above the CPU's."""
+    from audio_denoising_amd.pipeline import Denoiser
+    from oracle import dsp_ref, pipeline_ref
+    p = pipeline_ref.PARAMS_S
+    f64 = load_golden("metric_f64_B256.npz")
+    g = torch.Generator().manual_seed(int(f64["frames_seed"]))
+    frames = 0.1 * torch.randn(256, p.n_fft, generator=g)
+    init = torch.rand(256, p.n_stft, 3, dtype=torch.complex64, generator=torch.Generator().manual_seed(int(f64["init_seed"])))
+    dn = Denoiser(_model(dev, 5), p.sample_rate, p.n_fft, p.hop, p.n_mels)
+    out, hx, resid = dn.process_frame(frames.to(dev), None, init_angles=init.to(dev), return_residual=True)
+    fb = dsp_ref.melscale_fbanks(p.n_stft, p.n_mels, p.sample_rate)
+    with torch.no_grad():
+        ref = pipeline_ref.process_frame(_state_dict("dari_tult"), frames, torch.zeros(256, 17, 5), p, fb, init_angles=init)
+    eg = out.cpu().numpy().astype(np.float64) - f64["out"]
+    ec = ref["out"].numpy().astype(np.float64) - f64["out"]
+    g_rms, c_rms = np.sqrt((eg ** 2).mean(axis=1)), np.sqrt((ec ** 2).mean(axis=1))
+    g_max, c_max = np.abs(eg).max(axis=1), np.abs(ec).max(axis=1)
+    rg = np.abs(resid.cpu().numpy() - f64["predicted_diff"]).reshape(256, -1).max(axis=1)
+    rc = np.abs(ref["predicted_diff"].numpy() - f64["predicted_diff"]).reshape(256, -1).max(axis=1)
+    q = lambda a: f"median {np.median(a):.2e} p90 {np.quantile(a, .9):.2e} max {a.max():.2e}"
+    print(f"vs float64, per-stream waveform RMS: gpu {q(g_rms)} | cpu fp32 {q(c_rms)}")
+    print(f"vs float64, per-stream waveform max-abs: gpu {q(g_max)} | cpu fp32 {q(c_max)}")
+    print(f"vs float64, per-stream residual max-abs: gpu {q(rg)} | cpu fp32 {q(rc)}")
+    # What can be asserted per stream and what cannot.  A frame's error is its rounding times the amplification of 32 Griffin-Lim iterations that
+    # start from RANDOM phases, and that amplification is not a property of the frame alone: the float64 pipeline itself, fed the same frames
+    # perturbed by 6e-8 relative (one fp32 rounding), moves by a per-stream amount that differs by up to 300x between two draws of the
+    # perturbation (profiles/r04_parity_margins.txt).  So the per-stream RATIO of two fp32 implementations' errors is heavy-tailed in both
+    # directions (measured 0.004 .. 290, median 1.06) and "gpu <= 2 x cpu for every stream" is not satisfiable by any implementation, the
+    # reference's own included.  Asserted instead: the two error DISTRIBUTIONS over the 256 streams coincide -- every quantile of the GPU's
+    # within 2x of the CPU's, about half of the streams on either side, the GPU's batch RMS not above the CPU's -- and the mel residual and hx,
+    # which no chain amplifies, per stream.
+    for e_g, e_c, floor in ((g_rms, c_rms, 2e-8), (g_max, c_max, 2e-7)):
+        for x in (0.1, 0.25, 0.5, 0.75, 0.9, 0.99, 1.0):
+            assert np.quantile(e_g, x) <= 2 * np.quantile(e_c, x) + floor, (x, np.quantile(e_g, x), np.quantile(e_c, x))
+    worse = float((g_rms > c_rms).mean())
+    assert 0.3 <= worse <= 0.7, worse
+    assert np.sqrt((eg ** 2).mean()) <= 1.25 * np.sqrt((ec ** 2).mean())
+    for x in (0.5, 0.9, 1.0):
+        assert np.quantile(rg, x) <= 2 * np.quantile(rc, x), (x, np.quantile(rg, x), np.quantile(rc, x))
+    assert np.abs(hx.cpu().numpy() - f64["hx"]).max() <= GUARD_HX and rg.max() <= GUARD_RESIDUAL          # (every stream, absolute)
+    assert np.sqrt((eg ** 2).mean()) <= GUARD_B256_WAVE_RMS and g_max.max() <= GUARD_B256_WAVE_MAX and np.median(g_rms) <= GUARD_B256_STREAM_MEDIAN_RMS
+    # Without the chain's amplification the arithmetic can be pinned per stream: two iterations (four transforms each way, the phase update with
+    # momentum, the istft) against float64, every stream, at a band the tail cannot hide in
+    dn2 = Denoiser(_model(dev, 5), p.sample_rate, p.n_fft, p.hop, p.n_mels, n_iter=2)
+    o2, _ = dn2.process_frame(frames.to(dev), None, init_angles=init.to(dev))
+    y2 = _f64_frames([frames], [init], p, n_iter=2)[0][0]
+    e2 = o2.cpu().numpy().astype(np.float64) - y2
+    print(f"two iterations vs float64: per-stream max-abs {q(np.abs(e2).max(axis=1))}")
+    assert np.abs(e2).max() <= GUARD_WAVE_MAX
+
+
 @pytest.mark.parametrize("batch", [1, 3, 17, 255, 257, 1000])
 def test_odd_batch_sizes_pipelined_equal_serial_and_match_the_oracle(dev, batch):
     """Batch sizes around the switches in the launch logic: a single stream, sizes that are no multiple of anything, 255 / 257 on either side of
@@ -357,8 +443,12 @@ def test_odd_batch_sizes_pipelined_equal_serial_and_match_the_oracle(dev, batch)
     fb = dsp_ref.melscale_fbanks(p.n_stft, p.n_mels, p.sample_rate)
     with torch.no_grad():
         ref = pipeline_ref.process_frame(_state_dict("dari_tult"), hops[0][idx], torch.zeros(len(idx), 17, 5), p, fb, init_angles=init[idx])
-    assert (resid.cpu()[idx] - ref["predicted_diff"]).abs().max().item() <= TOL_RESIDUAL
+    assert (resid.cpu()[idx] - ref["predicted_diff"]).abs().max().item() <= GUARD_RESIDUAL
     _wave_close(out.cpu()[idx].numpy(), ref["out"].numpy())
+    # at the guard bands: against the float64 yardstick (two fp32 results of random frames differ by what Griffin-Lim makes of EITHER one's rounding)
+    y64, _ = _f64_frames([hops[0][idx]], [init[idx]], p)
+    e = out.cpu()[idx].numpy().astype(np.float64) - y64[0]
+    assert np.sqrt((e ** 2).mean()) <= GUARD_F64_WAVE_RMS and np.abs(e).max() <= GUARD_F64_WAVE_MAX, (np.sqrt((e ** 2).mean()), np.abs(e).max())
 
 
 def test_pipelined_hops_equal_serial_hops_bit_for_bit(dev):
@@ -1078,6 +1168,12 @@ def test_wavefront_per_stream_schedule_matches_the_oracle_at_1024_streams(dev):
             h = ref["hx"]
             _wave_close(outs[i].cpu()[idx].numpy(), ref["out"].numpy())
     assert (hx.cpu()[idx] - h).abs().max().item() <= TOL_HX_STREAM
+    # at the guard bands: both hops against the float64 yardstick
+    y64, h64 = _f64_frames([hh[idx] for hh in hops], [ia[idx] for ia in inits], p)
+    for i in range(2):
+        e = outs[i].cpu()[idx].numpy().astype(np.float64) - y64[i]
+        assert np.sqrt((e ** 2).mean()) <= GUARD_F64_WAVE_RMS and np.abs(e).max() <= GUARD_F64_WAVE_MAX, (i, np.sqrt((e ** 2).mean()), np.abs(e).max())
+    assert np.abs(hx.cpu()[idx].numpy() - h64).max() <= GUARD_HX
 
 
 @pytest.mark.parametrize("depth", [2, 3, 4])
