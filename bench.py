@@ -384,6 +384,26 @@ def side_measurement(args, dn, B, dev):
         def step(i):
             hs.push(hop_h, copy=False)
         fin = hs.drain
+    elif args.stream and args.group > 0:
+        # streaming hop groups (dn_pipe_stream_push_group): `group` hops in, `group` hops out per launch, whole Griffin-Lim chains
+        ps = PipelinedStream(dn, B)
+        ps.set_group(args.group)
+        hops = (0.1 * torch.randn(args.group, B, dn.hop, generator=g)).to(dev)
+        hops_out = torch.empty_like(hops)
+        mode = f"stream, groups of {args.group} hops per launch"
+        args.steps = max(1, args.steps // args.group) * args.group
+        args.warmup = -(-args.warmup // args.group) * args.group
+        if args.graph:
+            ps._bind()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                ps.push_group_(hops, hops_out, check_weights=False)
+            mode += " + hipGraph (one captured group push replayed)"
+
+        def step(i):
+            if i % args.group == 0:
+                graph.replay() if args.graph else ps.push_group_(hops, hops_out, check_weights=False)
+        fin = ps.flush_group
     elif args.stream:
         ps = PipelinedStream(dn, B)
         if args.depth > 0:
@@ -433,6 +453,20 @@ def side_measurement(args, dn, B, dev):
 
         def step(i):
             pipe.submit(frames, hx, out, seed=1000, check_weights=False)
+        fin = pipe.flush
+    elif args.group > 0 or (args.group < 0 and args.depth <= 0 and default_group(B, dn.n_fft) > 0):
+        G = args.group if args.group > 0 else default_group(B, dn.n_fft)
+        frames = (0.1 * torch.randn(G, B, dn.n_fft, generator=g)).to(dev)
+        outs = torch.empty_like(frames)
+        pipe = HopPipeline(dn, B)
+        pipe.set_group(G)
+        mode = f"frames, groups of {G} hops per launch"
+        args.steps = max(1, args.steps // G) * G
+        args.warmup = -(-args.warmup // G) * G
+
+        def step(i):
+            if i % G == 0:
+                pipe.submit_group(frames, hx, outs, seed=1000, check_weights=False)
         fin = pipe.flush
     else:
         frames = (0.1 * torch.randn(B, dn.n_fft, generator=g)).to(dev)
@@ -497,6 +531,8 @@ class Rehearsal:
     class _P:
         def __init__(self): self.done = []
         def submit(self, frames, hx, out, **kw): out.copy_(frames * 2.0)
+        def submit_group(self, frames, hx, out, **kw): out.copy_(frames * 2.0)
+        def set_group(self, hops): pass
         def flush(self): pass
 
     def __init__(self): self.device, self.n_fft = torch.device("cpu"), N_FFT
@@ -505,18 +541,20 @@ class Rehearsal:
     def process_frame_(self, frames, hx, out, **kw): out.copy_(frames * 2.0)
 
 
-def ingress_variant(dn, pipe, B, world, rank, dev, lo, steps, warmup, dist, backend, fence, on_gpu):
-    """Every step: scatter the N x 256 frames rank 0 holds -> hop -> gather the denoised frames on rank 0.
-    Transfers are issued on a second HIP stream, double-buffered: while hop i computes, hop i+1's frames arrive and hop
-    i-1's result leaves (the pipelined hop completes frame i-1 during launch i)."""
+def ingress_variant(dn, pipe, B, world, rank, dev, lo, steps, warmup, dist, backend, fence, on_gpu, group=0):
+    """Every step: scatter the N x 256 frames rank 0 holds -> hop -> gather the denoised frames on rank 0, on the HEADLINE's schedule:
+    the unit is one launch = `group` consecutive hops of every stream (`group` = 0: one hop per launch, the one-hop pipe).  Transfers are issued on a
+    second HIP stream, double-buffered: while launch i computes, the frames of launch i+1 arrive and the result of launch i-1 leaves (a launch
+    completes the Griffin-Lim of the hops the previous launch fronted)."""
     from audio_denoising_amd.shard import gather_rows, scatter_rows
     total = B * world
+    G = max(group, 1)
     cdev = dev if on_gpu else torch.device("cpu")
     g = torch.Generator().manual_seed(99)
-    big_in = (0.1 * torch.randn(total, N_FFT, generator=g)).to(cdev) if rank == 0 else None
-    big_out = torch.zeros(total, N_FFT, device=cdev) if rank == 0 else None
-    in_buf = [torch.empty(B, N_FFT, device=cdev) for _ in range(2)]
-    out_buf = [torch.zeros(B, N_FFT, device=cdev) for _ in range(2)]
+    big_in = (0.1 * torch.randn(G, total, N_FFT, generator=g)).to(cdev) if rank == 0 else None
+    big_out = torch.zeros(G, total, N_FFT, device=cdev) if rank == 0 else None
+    in_buf = [torch.empty(G, B, N_FFT, device=cdev) for _ in range(2)]
+    out_buf = [torch.zeros(G, B, N_FFT, device=cdev) for _ in range(2)]
     hx = dn.init_hx(B)
     if on_gpu:
         comm = torch.cuda.Stream(device=dev)
@@ -526,12 +564,21 @@ def ingress_variant(dn, pipe, B, world, rank, dev, lo, steps, warmup, dist, back
         ev_gth = [torch.cuda.Event() for _ in range(2)]
 
     def scatter(i):
-        scatter_rows(big_in, total, (N_FFT,), torch.float32, cdev, out=in_buf[i & 1])
+        for h in range(G):
+            scatter_rows(None if big_in is None else big_in[h], total, (N_FFT,), torch.float32, cdev, out=in_buf[i & 1][h])
 
     def gather(i):
-        gather_rows(out_buf[i & 1], total, out=big_out)
+        for h in range(G):
+            gather_rows(out_buf[i & 1][h], total, out=None if big_out is None else big_out[h])
 
-    def run(n):
+    def launch(s):
+        if group > 0:
+            pipe.submit_group(in_buf[s], hx, out_buf[s], seed=3000, stream_id0=lo, check_weights=False)
+        else:
+            pipe.submit(in_buf[s][0], hx, out_buf[s][0], seed=3000, stream_id0=lo, check_weights=False)
+
+    def run(n_hops):
+        n = -(-n_hops // G)                       # launches
         if on_gpu:
             with torch.cuda.stream(comm):
                 scatter(0)
@@ -540,17 +587,17 @@ def ingress_variant(dn, pipe, B, world, rank, dev, lo, steps, warmup, dist, back
                 s = i & 1
                 cur.wait_event(ev_in[s])
                 if i >= 3:
-                    cur.wait_event(ev_gth[s ^ 1])                    # launch i rewrites out_buf[(i-1)&1]: hop i-3's egress has left it
-                pipe.submit(in_buf[s], hx, out_buf[s], seed=3000, stream_id0=lo, check_weights=False)    # launch i: front of hop i, Griffin-Lim of hop i-1
+                    cur.wait_event(ev_gth[s ^ 1])                    # launch i rewrites out_buf[(i-1)&1]: the egress of launch i-3 has left it
+                launch(s)                                            # launch i: front halves of unit i, Griffin-Lim of unit i-1
                 ev_hop[s].record(cur)
                 with torch.cuda.stream(comm):
                     if i + 1 < n:
                         if i >= 1:
-                            comm.wait_event(ev_hop[s ^ 1])          # launch i-1 has read in_buf[(i+1)&1] (its front half is done)
+                            comm.wait_event(ev_hop[s ^ 1])          # launch i-1 has read in_buf[(i+1)&1] (its front halves are done)
                         scatter(i + 1)                               # overlaps launch i
                         ev_in[s ^ 1].record(comm)
                     if i >= 1:
-                        comm.wait_event(ev_hop[s])                   # launch i completed hop i-1 into out_buf[(i-1)&1]
+                        comm.wait_event(ev_hop[s])                   # launch i completed unit i-1 into out_buf[(i-1)&1]
                         gather(i - 1)                                # overlaps launch i+1
                         ev_gth[s ^ 1].record(comm)
             pipe.flush()
@@ -562,12 +609,13 @@ def ingress_variant(dn, pipe, B, world, rank, dev, lo, steps, warmup, dist, back
         else:
             for i in range(n):
                 scatter(i)
-                pipe.submit(in_buf[i & 1], hx, out_buf[i & 1], seed=3000, stream_id0=lo)
+                launch(i & 1)
                 gather(i)
-    run(max(2, warmup))
+        return n * G
+    run(max(2 * G, warmup))
     fence()
     t0 = time.perf_counter()
-    run(steps)
+    done = run(steps)
     fence()
     el = time.perf_counter() - t0
     if dist is not None:
@@ -577,7 +625,8 @@ def ingress_variant(dn, pipe, B, world, rank, dev, lo, steps, warmup, dist, back
     ok = True
     if rank == 0:
         ok = bool(torch.isfinite(big_out).all()) and float(big_out.abs().max()) > 0.0
-    return {"ingress": "scatter_gather", "value": round(total * steps / el, 1), "unit": "frames/s", "ms_per_step": round(1e3 * el / steps, 4),
+    return {"ingress": "scatter_gather", "value": round(total * done / el, 1), "unit": "frames/s", "ms_per_step": round(1e3 * el / done, 4),
+            "hops_per_launch": G, "schedule": "the headline's: hop groups" if group > 0 else "one hop per launch (one-hop pipe)",
             "bytes_per_step_each_way": total * N_FFT * 4, "backend": backend, "overlap": "second HIP stream, double-buffered" if on_gpu else "none (host rehearsal)",
             "root_output_finite": ok}
 
@@ -725,13 +774,16 @@ def main():
     if world > 1 and pipe is not None:
         # a side measurement must never cost the headline line: any failure in it (on every rank alike: the loop is collective) is reported, not raised
         try:
-            # (its double buffering is written for the one-hop pipe: hop i-1 completes during launch i)
+            # the headline's schedule: one launch = `group` hops (its double buffering needs only that launch i completes the unit launch i-1 fronted)
+            igroup = group if group > 0 else (int(os.environ.get("DN_REHEARSAL_GROUP", "0")) if rehearsal else 0)
             ipipe = dn.pipe(B) if rehearsal else HopPipeline(dn, B)
+            if igroup > 0:
+                ipipe.set_group(igroup)
 
             def ifence():
                 ipipe.flush()
                 fence()
-            ingress = ingress_variant(dn, ipipe, B, world, rank, dev, lo, args.steps, args.warmup, dist, backend, ifence, on_gpu)
+            ingress = ingress_variant(dn, ipipe, B, world, rank, dev, lo, args.steps, args.warmup, dist, backend, ifence, on_gpu, group=igroup)
         except Exception as e:          # noqa: BLE001
             ingress = {"ingress": "scatter_gather", "error": f"{type(e).__name__}: {e}"[:300]}
 

@@ -30,6 +30,15 @@ def test_bench_self_launches_two_gloo_ranks_and_reports_both_ingress_variants():
     assert iv["bytes_per_step_each_way"] == 12 * 1024 * 4 and iv["value"] > 0
 
 
+def test_bench_ingress_variant_runs_the_headlines_hop_groups_on_two_gloo_ranks():
+    """The scatter -> launch -> gather loop in units of four hops per launch (the headline's schedule since round 4), rank plumbing only."""
+    r = _run(["--gpus", "2", "--steps", "8", "--warmup", "1", "--batch", "5"], {"DN_BENCH_REHEARSAL": "1", "DN_DIST_BACKEND": "gloo", "DN_REHEARSAL_GROUP": "4"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    iv = d["ingress_variant"]
+    assert d["ingress_ok"] is True and iv["hops_per_launch"] == 4 and iv["root_output_finite"] is True and iv["value"] > 0
+
+
 def test_bench_refuses_a_rank_count_that_does_not_match():
     env = {"DN_BENCH_REHEARSAL": "1", "DN_DIST_BACKEND": "gloo", "WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}
     r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],

@@ -69,6 +69,8 @@ class _OneHopPipe:
             o.copy_(f * 2.0)
         self.pending = (frames.clone(), out)          # (the front half has consumed `frames` when submit returns: launch order)
 
+    submit_group = submit                             # (a hop group: the same hazards with G hops per launch -- frames / out are (G, B, n))
+
     def flush(self):
         if self.pending is not None:
             f, o = self.pending
@@ -76,7 +78,7 @@ class _OneHopPipe:
             self.pending = None
 
 
-def _ingress_worker(rank, world, port, total, steps, q):
+def _ingress_worker(rank, world, port, total, steps, q, group=1):
     """bench.ingress_variant's order of operations (there: scatter/gather on a second HIP stream with events between the same steps; here the
     calls themselves, in that order): scatter(0); per step i: hop(i) -> scatter(i+1) -> gather(i-1); flush; gather(n-1).  Every step carries
     different audio; in_buf / out_buf are double-buffered, `out=` forms, uneven shards."""
@@ -85,24 +87,33 @@ def _ingress_worker(rank, world, port, total, steps, q):
     try:
         lo, hi = shard_range(total, world, rank)
         B = hi - lo
-        audio = [torch.arange(total * 4, dtype=torch.float32).reshape(total, 4) + 1000.0 * i for i in range(steps)] if rank == 0 else [None] * steps
-        big_out = torch.zeros(total, 4) if rank == 0 else None
-        in_buf = [torch.empty(B, 4) for _ in range(2)]
-        out_buf = [torch.zeros(B, 4) for _ in range(2)]
+        G = group           # hops per launch (the headline's schedule: 4); a unit of audio is (G, total, 4)
+        audio = [torch.arange(G * total * 4, dtype=torch.float32).reshape(G, total, 4) + 1000.0 * i for i in range(steps)] if rank == 0 else [None] * steps
+        big_out = torch.zeros(G, total, 4) if rank == 0 else None
+        in_buf = [torch.empty(G, B, 4) for _ in range(2)]
+        out_buf = [torch.zeros(G, B, 4) for _ in range(2)]
         pipe = _OneHopPipe()
         ok = True
-        scatter_rows(audio[0], total, (4,), torch.float32, "cpu", out=in_buf[0])
+
+        def scatter(i, s):
+            for h in range(G):
+                scatter_rows(None if audio[i] is None else audio[i][h], total, (4,), torch.float32, "cpu", out=in_buf[s][h])
+
+        def gather(s):
+            for h in range(G):
+                gather_rows(out_buf[s][h], total, out=None if big_out is None else big_out[h])
+        scatter(0, 0)
         for i in range(steps):
             s = i & 1
-            pipe.submit(in_buf[s], out_buf[s])                    # launch i: front of hop i, completes hop i-1 into out_buf[(i-1)&1]
+            pipe.submit_group(in_buf[s], out_buf[s])              # launch i: front halves of unit i, completes unit i-1 into out_buf[(i-1)&1]
             if i + 1 < steps:
-                scatter_rows(audio[i + 1], total, (4,), torch.float32, "cpu", out=in_buf[s ^ 1])
+                scatter(i + 1, s ^ 1)
             if i >= 1:
-                gather_rows(out_buf[s ^ 1], total, out=big_out)
+                gather(s ^ 1)
                 if rank == 0:
                     ok = ok and bool(torch.equal(big_out, audio[i - 1] * 2.0))
         pipe.flush()
-        gather_rows(out_buf[(steps - 1) & 1], total, out=big_out)
+        gather((steps - 1) & 1)
         if rank == 0:
             ok = ok and bool(torch.equal(big_out, audio[steps - 1] * 2.0))
             q.put(ok)
@@ -110,17 +121,18 @@ def _ingress_worker(rank, world, port, total, steps, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("total", [5, 7])
-def test_double_buffered_ingress_order_round_trips_on_uneven_shards(total):
+@pytest.mark.parametrize("total,group", [(5, 1), (7, 1), (5, 4), (7, 4)])
+def test_double_buffered_ingress_order_round_trips_on_uneven_shards(total, group):
     """the scatter -> hop -> gather loop of bench.py's `ingress_variant`, with its double buffering and the one-hop delay of the
-    pipelined hop, on two gloo ranks with uneven shards (3 + 2, 4 + 3 rows): every step's audio must come back doubled, step by step."""
+    pipelined hop, on two gloo ranks with uneven shards (3 + 2, 4 + 3 rows): every step's audio must come back doubled, step by step -- one hop
+    per launch, and the headline's schedule since round 4: units of four hops per launch (bench.py: ingress_variant(group=4))."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_ingress_worker, args=(r, 2, port, total, 6, q)) for r in range(2)]
+    procs = [ctx.Process(target=_ingress_worker, args=(r, 2, port, total, 6, q, group)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
