@@ -992,7 +992,7 @@ int dn_pipe_set_group(dn_pipe* p, int32_t hops) {
     if (!p) return fail(DN_ERR_INVALID, "dn_pipe_set_group: null pipe");
     if (hops < 0 || hops > DN_PIPE_MAX_GROUP) return fail(DN_ERR_INVALID, "dn_pipe_set_group: hops must be in 0.." + std::to_string(DN_PIPE_MAX_GROUP));
     if (hops > 0 && p->d->cfg.n_fft != 1024)
-        return fail(DN_ERR_UNSUPPORTED, "hop groups run whole Griffin-Lim chains one wavefront per stream, which is built for n_fft 1024");
+        return fail(DN_ERR_UNSUPPORTED, "hop groups run whole Griffin-Lim chains one wavefront per stream, which is built for n_fft 1024 (at 1536 that form measured slower than a wavefront per column)");
     if (hops > 0 && p->depth > 1) return fail(DN_ERR_INVALID, "dn_pipe_set_group: the pipe is deeper than one hop (dn_pipe_set_depth(p, 1) first)");
     if (hops > 0 && p->hio) return fail(DN_ERR_UNSUPPORTED, "dn_pipe_set_group: the host-buffer transport moves single hops");
     if (hops == p->group) return DN_OK;
@@ -1143,8 +1143,10 @@ static int fill_hop_args(dn_pipe* p, dn::HopArgs& a, const float* init_angles, u
     const bool can_split = per_stream && p->gl_split == 0;
     a.split = can_split && (p->split == DN_SPLIT_ON || (p->split == DN_SPLIT_AUTO && (long)p->B * p->depth >= dn::kSplitAutoChains)) ? 1 : 0;
     a.prime = p->d->cfg.n_fft / p->d->cfg.hop - 1;
-    if (p->group > 0) {          // whole chains: one workgroup a stream, wavefront j the j-th pending frame (group_kernel)
-        a.glw = 1; a.depth = 1; a.spb = 1; a.back_blocks = p->B; a.split = 0; a.gl_split = 0;
+    if (p->group > 0) {          // whole chains (group_kernel): a workgroup's four wavefronts = spb streams x the pending frames of each
+        a.glw = 1; a.depth = 1; a.split = 0; a.gl_split = 0;
+        a.spb = p->group == 1 ? 4 : p->group == 2 ? 2 : 1;
+        a.back_blocks = (p->B + a.spb - 1) / a.spb;
     }
     return DN_OK;
 }

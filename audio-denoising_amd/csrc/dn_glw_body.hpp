@@ -22,6 +22,7 @@ namespace dn {
 // new signal, one transform -- does not fit the 256 registers of a wave that shares its SIMD: built and measured in round 3 (columns one after the other,
 // radix-12 twiddles in LDS, three streams a workgroup): 360-400 B of scratch a lane, 46 scratch accesses in every iteration, and 1.6x SLOWER than a
 // wavefront per column at 1,024 streams (662 against 410 us per hop), 1.7-2.3x slower as a deep pipe at 256.  Removed again; gl_body serves n_fft 1536.
+// (Round 4 tried it once more with a SIMD's registers to itself -- a chains-only kernel, 420 registers, nothing spilled: still slower, dn_group.hip.)
 constexpr int kGlwWaves = 4;          // wavefronts of a workgroup that run a chain (streams x chain segments)
 
 #ifdef DN_PROBE

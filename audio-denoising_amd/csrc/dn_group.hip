@@ -29,9 +29,13 @@ static __device__ unsigned long long g_group_wg[2048][2];
 
 template <int NFFT, bool STREAM, bool BF16, int CT>
 __global__ __launch_bounds__(kHopPipeThreads, 2) void group_kernel(DspDev d, CellDev cd, HopArgs a) {
-    static_assert(NFFT == 1024, "whole chains run one wavefront per stream (dn_glw_body.hpp): n_fft 1024");
+    // n_fft 1024 only.  At 1536 a chain wave needs the state of three columns of 768 complex values: 420 registers.  Built in round 4 as a split group
+    // (the chains as a launch of their own, one wave a SIMD, nothing spilled; the front halves as a second launch) and measured SLOWER than the one-hop
+    // pipe's wavefront per column: 118.6 against 95.8 us per batch-256 hop, 443 against 370 us at 1,024 streams -- one wave runs six 768-point
+    // transforms an iteration back to back (24 k ticks) where three column waves overlap theirs, and at 420 registers no front wave fits beside it.
+    static_assert(NFFT == 1024, "whole chains run one wavefront per stream beside a front wave (dn_glw_body.hpp): n_fft 1024");
     constexpr int kNR = NFFT, kBins = Geo<NFFT>::kBins, kHop = kNR / 2;
-    static_assert(kHopPipeThreads * 2 == kHop, "the ordered overlap-add fold: one sample pair of either half of the line per thread");
+    constexpr int kPairs = kHop / 2, kFoldN = (kPairs + kHopPipeThreads - 1) / kHopPipeThreads;   // sample pairs of half an overlap-add line, per thread (1 at n_fft 1024, 2 at 1536)
     __shared__ __attribute__((aligned(16))) char smem[hop_smem<NFFT>()];
     const int tid = threadIdx.x;
     const unsigned long long pushes = a.ctl->pushes, frames = a.ctl->frames;
@@ -46,16 +50,19 @@ __global__ __launch_bounds__(kHopPipeThreads, 2) void group_kernel(DspDev d, Cel
     const int fronted = a.front_B > 0 ? a.group_hops - prime_hops : 0;
     DN_GWG(0);
     if ((int)blockIdx.x < a.back_blocks) {
-        const size_t b = blockIdx.x;
+      {
+        // a workgroup holds a.spb streams x `per` pending frames of each (spb x per = 4): wave w runs frame w % per of stream blockIdx.x * spb + w / per
         const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int per = kGlwWaves / a.spb, sidx = wv / per, j = wv - sidx * per;
+        const size_t b = (size_t)blockIdx.x * a.spb + sidx;
         DN_WSTAMP(0);
-        const bool runs = wv < (int)pending;
+        const bool runs = j < (int)pending && b < (size_t)a.back_B;
         if (pending && !runs) {            // (the workgroup's window tables: every wave fills its share; a wave with a chain does it inside glw_body)
             glw_fill_tables<NFFT, kHopPipeThreads>(smem, d, tid);
             DN_LDS_BARRIER();
         }
         if (runs) {
-            const int s = slot_behind(slot_next, (int)pending - wv, a.n_slots);
+            const int s = slot_behind(slot_next, (int)pending - j, a.n_slots);
             const float* slot = a.slots + (size_t)s * a.slot_stride;
             const uint32_t* meta = reinterpret_cast<const uint32_t*>(slot + sl.meta) + kSlotMeta * b;
             const v2f* init = meta[0] ? reinterpret_cast<const v2f*>(a.slot_init + (size_t)s * a.init_stride) : nullptr;
@@ -69,38 +76,58 @@ __global__ __launch_bounds__(kHopPipeThreads, 2) void group_kernel(DspDev d, Cel
             DN_WSTAMP(7);
         }
         if (STREAM) {
-            // P12 for the frames of this stream in order: hop_out <- ola[:hop]; ola <- concat(ola[hop:], 0) + frame * peak (app3.py:217-224).  The chains
-            // left frame x 1/envelope in their LDS lines; a thread owns one sample pair of either half of the line and keeps both in registers.
+            // P12 for the frames of a stream in order: hop_out <- ola[:hop]; ola <- concat(ola[hop:], 0) + frame * peak (app3.py:217-224).  The chains
+            // left frame x 1/envelope in their LDS lines; a thread owns sample pairs of either half of the line and keeps both in registers.
             __syncthreads();
-            float* orow = a.ola + b * kNR;
-            const int n = 2 * tid, P = (int)pending;
+            const int P = (int)pending;
             const int lead = a.filler_first ? a.group_out - P : 0;          // hops with no frame behind them: zero, as the reference's ola still is
-            v2f lo = *reinterpret_cast<const v2f*>(orow + n), hi = *reinterpret_cast<const v2f*>(orow + n + kHop);
-            for (int i = 0; i < a.group_out; ++i) {
-                const int f = i - lead;
-                v2f emit = mk2(0.0f, 0.0f);
-                if (f >= 0 && f < P) {
-                    emit = lo;
-                    const float* line = glw_signal_line<NFFT>(smem, f);
-                    const v2f p0 = *reinterpret_cast<const v2f*>(line + n), p1 = *reinterpret_cast<const v2f*>(line + n + kHop);
-                    const float sc = (a.slots + (size_t)slot_behind(slot_next, P - f, a.n_slots) * a.slot_stride + sl.peak)[b];
-                    lo = mk2(fmaf(p0[0], sc, hi[0]), fmaf(p0[1], sc, hi[1]));
-                    hi = mk2(fmaf(p1[0], sc, 0.0f), fmaf(p1[1], sc, 0.0f));
+            for (int si = 0; si < a.spb; ++si) {
+                const size_t bs = (size_t)blockIdx.x * a.spb + si;
+                if (bs >= (size_t)a.back_B) break;
+                float* orow = a.ola + bs * kNR;
+                v2f lo[kFoldN], hi[kFoldN];
+#pragma unroll
+                for (int r = 0; r < kFoldN; ++r) {
+                    const int m = tid + kHopPipeThreads * r;
+                    if (m < kPairs) { lo[r] = *reinterpret_cast<const v2f*>(orow + 2 * m); hi[r] = *reinterpret_cast<const v2f*>(orow + 2 * m + kHop); }
                 }
-                const size_t at = (size_t)i * (size_t)a.hop_out_stride + b * kHop + n;
-                if (a.out_s16) {
-                    const float c0 = fminf(fmaxf(emit[0], -1.0f), 1.0f) * 32767.0f, c1 = fminf(fmaxf(emit[1], -1.0f), 1.0f) * 32767.0f;   // app3.py:244-245
-                    *reinterpret_cast<unsigned int*>(static_cast<short*>(a.hop_out) + at) = (unsigned int)(unsigned short)(short)c0 | ((unsigned int)(unsigned short)(short)c1 << 16);
-                } else {
-                    *reinterpret_cast<v2f*>(static_cast<float*>(a.hop_out) + at) = emit;
+                for (int i = 0; i < a.group_out; ++i) {
+                    const int f = i - lead;
+                    const bool has = f >= 0 && f < P;
+                    const float* line = glw_signal_line<NFFT>(smem, si * per + (has ? f : 0));
+                    const float sc = has ? (a.slots + (size_t)slot_behind(slot_next, P - f, a.n_slots) * a.slot_stride + sl.peak)[bs] : 0.0f;
+#pragma unroll
+                    for (int r = 0; r < kFoldN; ++r) {
+                        const int m = tid + kHopPipeThreads * r;
+                        if (m >= kPairs) continue;
+                        v2f emit = mk2(0.0f, 0.0f);
+                        if (has) {
+                            emit = lo[r];
+                            const v2f p0 = *reinterpret_cast<const v2f*>(line + 2 * m), p1 = *reinterpret_cast<const v2f*>(line + 2 * m + kHop);
+                            lo[r] = mk2(fmaf(p0[0], sc, hi[r][0]), fmaf(p0[1], sc, hi[r][1]));
+                            hi[r] = mk2(fmaf(p1[0], sc, 0.0f), fmaf(p1[1], sc, 0.0f));
+                        }
+                        const size_t at = (size_t)i * (size_t)a.hop_out_stride + bs * kHop + 2 * m;
+                        if (a.out_s16) {
+                            const float c0 = fminf(fmaxf(emit[0], -1.0f), 1.0f) * 32767.0f, c1 = fminf(fmaxf(emit[1], -1.0f), 1.0f) * 32767.0f;   // app3.py:244-245
+                            *reinterpret_cast<unsigned int*>(static_cast<short*>(a.hop_out) + at) = (unsigned int)(unsigned short)(short)c0 | ((unsigned int)(unsigned short)(short)c1 << 16);
+                        } else {
+                            *reinterpret_cast<v2f*>(static_cast<float*>(a.hop_out) + at) = emit;
+                        }
+                    }
                 }
-            }
-            if (P > 0) {
-                *reinterpret_cast<v2f*>(orow + n) = lo;
-                *reinterpret_cast<v2f*>(orow + n + kHop) = hi;
+                if (P > 0) {
+#pragma unroll
+                    for (int r = 0; r < kFoldN; ++r) {
+                        const int m = tid + kHopPipeThreads * r;
+                        if (m < kPairs) { *reinterpret_cast<v2f*>(orow + 2 * m) = lo[r]; *reinterpret_cast<v2f*>(orow + 2 * m + kHop) = hi[r]; }
+                    }
+                }
             }
         }
+      }
     } else {
+      {
         const size_t b = blockIdx.x - a.back_blocks;
 #pragma unroll 1
         for (int h = 0; h < a.group_hops; ++h) {
@@ -154,6 +181,7 @@ __global__ __launch_bounds__(kHopPipeThreads, 2) void group_kernel(DspDev d, Cel
             }
             __syncthreads();          // the next hop reuses the LDS stages and reads the hx this one stored
         }
+      }
     }
     // ---- ticket: the last workgroup of the launch advances the control block (every workgroup has read it by then)
     __syncthreads();
@@ -175,12 +203,7 @@ __global__ __launch_bounds__(kHopPipeThreads, 2) void group_kernel(DspDev d, Cel
 
 void launch_group(const DspDev& d, const CellDev& c, const HopArgs& a, bool bf16, hipStream_t st) {
     const dim3 grid(a.back_blocks + a.front_B), block(kHopPipeThreads);
-#ifdef DN_GROUP_ONE          // (experiment builds: one instantiation)
-    hipLaunchKernelGGL((group_kernel<1024, false, false, 5>), grid, block, 0, st, d, c, a);
-    return;
-#endif
-    const bool stream = a.ola != nullptr;
-    const bool usual = a.C == 5;
+    const bool stream = a.ola != nullptr, usual = a.C == 5;
     auto go = [&](auto k) { hipLaunchKernelGGL(k, grid, block, 0, st, d, c, a); };
     if (stream) {
         if (usual) { if (bf16) go(group_kernel<1024, true, true, 5>); else go(group_kernel<1024, true, false, 5>); }

@@ -53,7 +53,6 @@ static __device__ unsigned int g_hop_blk_hw[2048];          // where every workg
 //      workgroups (the low block ids) run first and its front workgroups after them anyway -- two phases, not a mix -- and a front workgroup
 //      compiled beside the chain inherits the chain's 243 registers: two workgroups a CU.  On its own the front half is capped at
 //      kFrontPerCu workgroups a CU (its phases end at workgroup barriers and wait on memory: more of them in flight is what it wants).
-constexpr int kFrontPerCu = 4;
 template <int NFFT, bool STREAM, bool BF16, int CT, bool GLW, bool FRONT = false>
 __global__ __launch_bounds__(kHopPipeThreads, FRONT ? kFrontPerCu : (NFFT == 1536 || GLW) ? 2 : 1) void hop_kernel(DspDev d, CellDev cd, HopArgs a) {
     constexpr int kNR = NFFT, kBins = Geo<NFFT>::kBins;

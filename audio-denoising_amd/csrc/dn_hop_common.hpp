@@ -17,6 +17,7 @@ constexpr int kHopPipeThreads = 256;      // workgroup size of the fused launche
 #ifndef DN_HS_PRIO
 #define DN_HS_PRIO 1
 #endif
+constexpr int kFrontPerCu = 4;            // front workgroups a CU when they run as a launch of their own (hop_kernel<.., FRONT>, group_kernel<.., kGroupFronts>)
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 template <int NFFT> constexpr int hop_smem() {
     return cmax(cmax(cmax(kCellSmem, gl_smem<NFFT>()), cmax(stft_smem<NFFT>(), kInvSmem)), NFFT == 1024 ? glw_smem<1024>() : 0);

@@ -622,34 +622,40 @@ class QueuedPipelinedStreams(_Queues):
 
 
 def throughput_plan(batch: int, n_fft: int = 1024) -> dict:
-    """How to run ``batch`` independent streams on one MI355X for throughput, by the measurements in DESIGN.md (sections 4.6-4.9;
-    ``profiles/r03_v6_*``): ``{"queues", "pipes", "depth", "split"}`` for ``hop_pipeline`` / ``QueuedHopPipelines``.  Every choice gives the
-    same samples; what changes is the number of hops between a submit and its output (``depth``).
-      up to 384 streams    one pipe, four hops in flight (batch 256: 45.8 us per hop against 56.0 at depth 1)
-      385 .. 1,023         one pipe, two hops in flight
+    """How to run ``batch`` independent streams on one MI355X for throughput, by the measurements in DESIGN.md (sections 4.6-4.10;
+    ``profiles/r03_v6_*``, ``profiles/r04_group_sweep.txt``): ``{"queues", "pipes", "depth", "split", "group"}`` for ``hop_pipeline`` /
+    ``QueuedHopPipelines``.  Every choice gives the same samples; what changes is how many hops lie between handing a hop over and its output.
+    ``group`` > 0: input that can be handed over ``group`` hops at a time goes through hop groups (``submit_group``: whole Griffin-Lim chains
+    per launch, nothing parked); ``depth`` is what a caller that submits hop by hop gets instead.
+      up to 384 streams    one pipe; groups of four hops (batch 256: 40.0 us per hop) -- hop by hop: four hops in flight (45.8 us; 56.0 at depth 1)
+      385 .. 1,023         one pipe; groups of two hops, two streams a chain workgroup (512 streams: 6.5 M frames/s) -- hop by hop: depth 2 (6.1 M)
       1,024 .. 2,047       two pipes on two HIP streams, split hops, two hops in flight (1,024 streams: 7.6 M frames/s against 6.7 M)
       2,048 and up         an even number of pipes of about 1,024 streams, taking turns on two HIP streams, split hops, one hop in flight
                            (2,048 / 4,096 / 8,192 streams: 8.0 M frames/s against 7.0 / 7.3 / 7.6 M for one pipe)
     n_fft 1536 (the wavefront-per-stream schedule is not built there): one pipe at depth 1."""
     if n_fft != 1024:
-        return {"queues": 1, "pipes": 1, "depth": 1, "split": False}
+        return {"queues": 1, "pipes": 1, "depth": 1, "split": False, "group": 0}
     if batch <= 384:
-        return {"queues": 1, "pipes": 1, "depth": 4, "split": False}
+        return {"queues": 1, "pipes": 1, "depth": 4, "split": False, "group": 4}
     if batch < 1024:
-        return {"queues": 1, "pipes": 1, "depth": 2, "split": False}
+        return {"queues": 1, "pipes": 1, "depth": 2, "split": False, "group": 2}
     if batch < 2048:
-        return {"queues": 2, "pipes": 2, "depth": 2, "split": True}
-    return {"queues": 2, "pipes": 2 * (batch // 2048), "depth": 1, "split": True}
+        return {"queues": 2, "pipes": 2, "depth": 2, "split": True, "group": 0}
+    return {"queues": 2, "pipes": 2 * (batch // 2048), "depth": 1, "split": True, "group": 0}
 
 
-def hop_pipeline(denoiser: "Denoiser", batch: int):
+def hop_pipeline(denoiser: "Denoiser", batch: int, grouped: bool = False):
     """The frame-mode pipe ``throughput_plan`` picks for ``batch`` streams: a ``HopPipeline`` or ``QueuedHopPipelines`` (same ``submit`` /
-    ``flush``; the queued form also wants ``after()`` / ``before()`` or ``synchronize()`` around the caller's own stream)."""
+    ``flush``; the queued form also wants ``after()`` / ``before()`` or ``synchronize()`` around the caller's own stream).  ``grouped``: the caller
+    hands hops over in groups (``submit_group`` with ``pipe.group`` hops at a time) where the plan has a group size."""
     plan = throughput_plan(batch, denoiser.n_fft)
     if plan["queues"] > 1:
         return QueuedHopPipelines(denoiser, batch, queues=plan["queues"], depth=plan["depth"], split=plan["split"], pipes=plan["pipes"])
     pipe = HopPipeline(denoiser, batch)
-    pipe.set_depth(plan["depth"])
+    if grouped and plan["group"] > 0:
+        pipe.set_group(plan["group"])
+    else:
+        pipe.set_depth(plan["depth"])
     return pipe
 
 

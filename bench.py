@@ -126,7 +126,11 @@ def default_depth(batch, n_fft):
 def default_group(batch, n_fft):
     """Hops per launch (dn_pipe_set_group) for throughput: with about one stream per CU (up to 384 streams) a launch carries four consecutive hops
     of every stream and the WHOLE Griffin-Lim chains of the previous four -- the occupancy of the depth-4 pipe without its parked chains."""
-    return 4 if n_fft == 1024 and batch <= 384 else 0
+    if n_fft != 1024:
+        return 0
+    # (measured, profiles/r04_group_sweep.txt: 384 streams 5.88 M frames/s against 5.32 M at depth 4; 512 / 768 streams as groups of two, two streams a
+    # workgroup: 6.52 / 6.52 M against 6.13 / 6.34 M at depth 2; from 1,024 streams the one-hop pipe with a wavefront per stream is faster: 6.73 against 6.42 M)
+    return 4 if batch <= 384 else 2 if batch < 1024 else 0
 
 
 def prewarm(step, seconds=0.3):
@@ -157,6 +161,28 @@ def time_pipe(dn, B, dev, steps, depth=1, seconds=None):
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     return B * steps / el, 1e3 * el / steps
+
+
+def time_group(dn, B, dev, steps, group):
+    """frames/s of hop groups at batch B (dn_pipe_submit_group: `group` hops per launch, whole Griffin-Lim chains): steady state + flush."""
+    from audio_denoising_amd.pipeline import HopPipeline
+    g = torch.Generator().manual_seed(4321)
+    frames = (0.1 * torch.randn(group, B, dn.n_fft, generator=g)).to(dev)
+    hx = dn.init_hx(B)
+    out = torch.empty_like(frames)
+    pipe = HopPipeline(dn, B)
+    pipe.set_group(group)
+    prewarm(lambda: pipe.submit_group(frames, hx, out, seed=1, check_weights=False), 0.3)
+    pipe.flush()
+    torch.cuda.synchronize()
+    n = max(1, steps // group)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        pipe.submit_group(frames, hx, out, seed=1, check_weights=False)
+    pipe.flush()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    return B * n * group / el, 1e3 * el / (n * group)
 
 
 def time_queued(dn, B, dev, steps, queues=2, depth=2, pipes=None):
@@ -191,13 +217,13 @@ def extra_measurements(args, dev, budget_steps=1500):
     res = {}
     # config 3
     dnb = build_denoiser(dev, "S", "bf16")
-    v, ms = time_pipe(dnb, BATCH, dev, 1000, default_depth(BATCH, N_FFT))
+    v, ms = time_group(dnb, BATCH, dev, 1000, default_group(BATCH, N_FFT))          # the headline's schedule (hop groups of four), bf16 conv tiles
     g = torch.Generator().manual_seed(1)
     fr = (0.1 * torch.randn(BATCH, N_FFT, generator=g)).to(dev)
     kt = staged_kernel_times(dnb, fr, dnb.init_hx(BATCH), 300)
     conv = CONV_FLOP_PER_FRAME * BATCH / (kt["cell"] * 1e-3) / 1e12
     res["config3_bf16"] = {"value": round(v, 1), "unit": "frames/s", "ms_per_step": round(ms, 4), "streams": BATCH,
-                           "pipeline_depth": default_depth(BATCH, N_FFT), "cell_ms": round(kt["cell"], 4),
+                           "hops_per_launch": default_group(BATCH, N_FFT), "cell_ms": round(kt["cell"], 4),
                            "conv_mfma": {"achieved": round(conv, 3), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(conv / PEAK_BF16_TFLOPS, 5)}}
     # config 5, one GPU's share: 1,024 streams, streaming state on the device, one captured push per hop
     dn = build_denoiser(dev, "S", "fp32")
@@ -255,6 +281,11 @@ def extra_measurements(args, dev, budget_steps=1500):
     qs8.flush()
     res["config5_stream_graph_1024"]["two_queues_depth2"]["graph_of_8_hops"] = {"value": round(B5 * (n5 // K8) * K8 / el, 1), "unit": "frames/s",
                                                                                 "ms_per_step": round(1e3 * el / ((n5 // K8) * K8), 4)}
+    # between one stream per CU and saturation: 512 streams as groups of two hops (two streams a chain workgroup) against the depth-2 pipe
+    v, ms = time_group(dn, 512, dev, 600, default_group(512, N_FFT))
+    v2, ms2 = time_pipe(dn, 512, dev, 600, 2)
+    res["batch_512"] = {"value": round(v, 1), "unit": "frames/s", "ms_per_step": round(ms, 4), "hops_per_launch": default_group(512, N_FFT),
+                        "fp32_frac": round(TOTAL_FLOP_PER_FRAME * v / 1e12 / PEAK_FP32_TFLOPS, 4), "depth2_value": round(v2, 1), "depth2_ms_per_step": round(ms2, 4)}
     # saturated regime (wavefront-per-stream Griffin-Lim)
     for b, n in ((1024, 300), (8192, 40)):
         v, ms = time_pipe(dn, b, dev, n, 1)

@@ -271,7 +271,7 @@ int dn_pipe_set_head_start(dn_pipe* p, int32_t iterations);
  * Call while nothing is in flight (after create or flush); synchronises the device. */
 #define DN_PIPE_MAX_DEPTH 4
 int dn_pipe_set_depth(dn_pipe* p, int32_t depth);
-/* Hop groups (n_fft 1024; DN_ERR_UNSUPPORTED at 1536): the loop body of app3.py:178-226 for `hops` CONSECUTIVE hops of every stream in ONE launch.
+/* Hop groups (n_fft 1024; DN_ERR_UNSUPPORTED at 1536, where the form measured slower than the one-hop pipe): the loop body of app3.py:178-226 for `hops` CONSECUTIVE hops of every stream in ONE launch.
  * A deep pipe (above) pays for every launch boundary inside a Griffin-Lim chain: the chain parks in HBM and comes back at the head of the next
  * launch.  With dn_pipe_set_group(p, H), 1 <= H <= DN_PIPE_MAX_GROUP, a launch is as long as a chain instead: dn_pipe_submit_group carries up to H
  * new hops of every stream -- hop h of the group reads frames + h * frames_stride, its front half (P1-P10) runs behind hop h-1's with hx handed on,
@@ -283,6 +283,7 @@ int dn_pipe_set_depth(dn_pipe* p, int32_t depth);
  * (hop_out + i * out_stride); the emitted stream is the one-hop pipe's delayed by H - 1 more hops (zeros until then), and
  * dn_pipe_stream_flush_group emits the frames still pending first and zero hops behind them (always H hops; *hops_valid, may be NULL, says how
  * many carry samples as far as this host thread's own pushes tell -- after graph replays ask dn_pipe_get_counters for `pending` before the flush).
+ * With H < 4 a workgroup's four wavefronts serve 4 / H streams (H = 2: two streams a workgroup -- what 512 to 768 streams per GPU want).
  * dn_pipe_set_group: call while nothing is in flight; H = 0 returns the pipe to single hops; synchronises the device; excludes depth > 1, a head
  * start and the host-buffer transport.  dn_pipe_submit on a group pipe is a group of one hop. */
 #define DN_PIPE_MAX_GROUP 4

@@ -502,7 +502,7 @@ def test_mel_stages_at_a_filter_count_that_is_not_a_multiple_of_16(lib):
         lib.dn_dsp_destroy(h)
 
 
-def _run_pipe(lib, dsp, m, schedule, B, n_hops, g, head_start=0, stream=False, s16=False, init=None, n_iter=6, depth=1, flush_after=None, split=None):
+def _run_pipe(lib, dsp, m, schedule, B, n_hops, g, head_start=0, stream=False, s16=False, init=None, n_iter=6, depth=1, flush_after=None, split=None, P=P):
     """n_hops pipelined hops (frame mode or streaming mode) under one Griffin-Lim schedule; returns everything a hop leaves behind"""
     from audio_denoising_amd._lib import DN_GL_WAVE_PER_STREAM  # noqa: F401
     pipe = C.c_void_p()
@@ -515,7 +515,7 @@ def _run_pipe(lib, dsp, m, schedule, B, n_hops, g, head_start=0, stream=False, s
         lib.check(lib.dn_pipe_set_split(pipe, split))
     outs = []
     if not stream:
-        hx = np.zeros((B, 17, 5), np.float32)
+        hx = np.zeros((B, 17, P.num_compressed_bins), np.float32)
         frames = [emu.f32(g["signal"][:B, h * P.hop: h * P.hop + P.n_fft]) for h in range(n_hops)]
         outs = [np.zeros((B, P.n_fft), np.float32) for _ in range(n_hops)]
         for h in range(n_hops):
@@ -536,7 +536,7 @@ def _run_pipe(lib, dsp, m, schedule, B, n_hops, g, head_start=0, stream=False, s
             o = np.zeros((B, P.hop), dt)
             lib.check(lib.dn_pipe_stream_flush(pipe, emu.ptr(o), int(s16), n_iter, 0.99, None))
             outs.append(o)
-        ring, ola, hx = np.zeros((B, P.n_fft), np.float32), np.zeros((B, P.n_fft), np.float32), np.zeros((B, 17, 5), np.float32)
+        ring, ola, hx = np.zeros((B, P.n_fft), np.float32), np.zeros((B, P.n_fft), np.float32), np.zeros((B, 17, P.num_compressed_bins), np.float32)
         lib.check(lib.dn_pipe_stream_get_state(pipe, emu.ptr(ring), emu.ptr(ola), emu.ptr(hx), None))
         outs += [ring, ola, hx]
     lib.dn_pipe_destroy(pipe)
@@ -602,7 +602,7 @@ def test_deep_pipe_runs_the_chain_in_segments_bit_identically(lib, dsp, depth):
         assert np.array_equal(x, y)
 
 
-def _run_groups(lib, dsp, m, B, n_hops, g, H, sizes=None, stream=False, s16=False, init=None, n_iter=4):
+def _run_groups(lib, dsp, m, B, n_hops, g, H, sizes=None, stream=False, s16=False, init=None, n_iter=4, P=P):
     """the same hops as _run_pipe, submitted as groups (dn_pipe_set_group): `sizes` = hops per submit (frame mode; default H each)"""
     pipe = C.c_void_p()
     create = lib.dn_pipe_stream_create if stream else lib.dn_pipe_create
@@ -610,7 +610,7 @@ def _run_groups(lib, dsp, m, B, n_hops, g, H, sizes=None, stream=False, s16=Fals
     lib.check(lib.dn_pipe_set_group(pipe, H))
     outs = []
     if not stream:
-        hx = np.zeros((B, 17, 5), np.float32)
+        hx = np.zeros((B, 17, P.num_compressed_bins), np.float32)
         frames = emu.f32(np.stack([g["signal"][:B, h * P.hop: h * P.hop + P.n_fft] for h in range(n_hops)]))
         out = np.zeros((n_hops, B, P.n_fft), np.float32)
         ia = None if init is None else emu.f32(np.stack(init))
@@ -638,7 +638,7 @@ def _run_groups(lib, dsp, m, B, n_hops, g, H, sizes=None, stream=False, s16=Fals
         valid = C.c_int32(-1)
         lib.check(lib.dn_pipe_stream_flush_group(pipe, emu.ptr(o), B * P.hop, int(s16), C.byref(valid), None))
         outs += [o[i] for i in range(H)]
-        ring, ola, hx = np.zeros((B, P.n_fft), np.float32), np.zeros((B, P.n_fft), np.float32), np.zeros((B, 17, 5), np.float32)
+        ring, ola, hx = np.zeros((B, P.n_fft), np.float32), np.zeros((B, P.n_fft), np.float32), np.zeros((B, 17, P.num_compressed_bins), np.float32)
         lib.check(lib.dn_pipe_stream_get_state(pipe, emu.ptr(ring), emu.ptr(ola), emu.ptr(hx), None))
         outs += [valid.value, ring, ola, hx]
     lib.dn_pipe_destroy(pipe)

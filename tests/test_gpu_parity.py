@@ -1392,8 +1392,9 @@ def test_hop_groups_refuse_what_they_do_not_run_and_replay_under_a_graph(dev):
     and one captured dn_pipe_stream_push_group replayed: the control block advances on the device, so replays equal eager pushes bit for bit."""
     from audio_denoising_amd._lib import DnError
     from audio_denoising_amd.pipeline import Denoiser, HopPipeline, PipelinedStream
-    p, r1 = _params("S"), _params("R1")
+    p = _params("S")
     dn = Denoiser(_model(dev, 5), p.sample_rate, p.n_fft, p.hop, p.n_mels)
+    r1 = _params("R1")
     with pytest.raises(DnError, match="1024"):
         HopPipeline(Denoiser(_model(dev, 4), r1.sample_rate, r1.n_fft, r1.hop, r1.n_mels), 4).set_group(2)
     pipe = HopPipeline(dn, 4)
@@ -1708,9 +1709,10 @@ def test_hop_pipeline_picks_the_planned_composition(dev):
     from audio_denoising_amd.pipeline import Denoiser, HopPipeline, QueuedHopPipelines, hop_pipeline
     p = _params("S")
     dn = Denoiser(_model(dev, 5), p.sample_rate, p.n_fft, p.hop, p.n_mels, n_iter=4)
-    a, b = hop_pipeline(dn, 1024), hop_pipeline(dn, 300)
+    a, b, c = hop_pipeline(dn, 1024), hop_pipeline(dn, 300), hop_pipeline(dn, 600, grouped=True)
     assert isinstance(a, QueuedHopPipelines) and len(a.pipes) == 2 and a.depth == 2 and [q.batch for q in a.pipes] == [512, 512]
-    assert isinstance(b, HopPipeline) and b.depth == 4
+    assert isinstance(b, HopPipeline) and b.depth == 4 and b.group == 0
+    assert isinstance(c, HopPipeline) and c.group == 2 and hop_pipeline(dn, 300, grouped=True).group == 4
     frames = 0.1 * torch.randn(1024, p.n_fft, device=dev)
     hx, out = dn.init_hx(1024), torch.zeros(1024, p.n_fft, device=dev)
     torch.cuda.synchronize()

@@ -136,11 +136,11 @@ def test_product_package_never_imports_the_oracle():
 def test_throughput_plan_follows_the_measured_thresholds():
     """pipeline.throughput_plan: pure host logic (DESIGN.md sections 4.6-4.9) -- which composition of pipes, depth and split a batch gets."""
     from audio_denoising_amd.pipeline import throughput_plan
-    one = lambda d, sp=False: {"queues": 1, "pipes": 1, "depth": d, "split": sp}  # noqa: E731
-    assert throughput_plan(256) == one(4)                                              # the metric's configuration
-    assert throughput_plan(384) == one(4) and throughput_plan(385) == one(2) == throughput_plan(1023)
-    assert throughput_plan(1024) == {"queues": 2, "pipes": 2, "depth": 2, "split": True}           # configs 4 / 5: 1,024 streams per GPU
-    assert throughput_plan(2048) == {"queues": 2, "pipes": 2, "depth": 1, "split": True} == throughput_plan(3072)
+    one = lambda d, g=0, sp=False: {"queues": 1, "pipes": 1, "depth": d, "split": sp, "group": g}  # noqa: E731
+    assert throughput_plan(256) == one(4, 4)                                           # the metric's configuration: groups of four hops
+    assert throughput_plan(384) == one(4, 4) and throughput_plan(385) == one(2, 2) == throughput_plan(1023)
+    assert throughput_plan(1024) == {"queues": 2, "pipes": 2, "depth": 2, "split": True, "group": 0}           # configs 4 / 5: 1,024 streams per GPU
+    assert throughput_plan(2048) == {"queues": 2, "pipes": 2, "depth": 1, "split": True, "group": 0} == throughput_plan(3072)
     assert throughput_plan(4096)["pipes"] == 4 and throughput_plan(6144)["pipes"] == 6 and throughput_plan(8192)["pipes"] == 8
     assert all(throughput_plan(b)["pipes"] % 2 == 0 for b in range(1024, 20000, 512))   # (an odd number of pipes on two queues measured slower)
     assert throughput_plan(1024, n_fft=1536) == one(1)
