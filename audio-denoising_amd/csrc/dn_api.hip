@@ -111,6 +111,7 @@ std::vector<float> smear_table(const float* offset, int L) {
 struct BiasSet {
     DevArena arena;
     dn::CellDev view;
+    dn::CellDev* view_dev = nullptr;      // the same view in device memory (group_kernel reads its pointers where it needs them: no kernel-argument copy)
 };
 
 }  // namespace
@@ -131,6 +132,7 @@ struct dn_dsp {
     dn_dsp_cfg cfg;
     DevArena arena;
     dn::DspDev view;
+    dn::DspDev* view_dev = nullptr;        // the same view in device memory (group_kernel)
     std::vector<float> fb, pinv, window;   // host copies [K][M], [K][M], [N]
 };
 
@@ -262,6 +264,13 @@ int build_bias(dn_model* m, int C, BiasSet** out) {
     }
     bs->view.w_gh = m->packed.ptr<float>(m->off_gh);
     bs->view.bt_gh = bs->arena.ptr<float>(o_gh);
+    e = hipMalloc(reinterpret_cast<void**>(&bs->view_dev), sizeof(dn::CellDev));
+    if (e == hipSuccess) e = hipMemcpy(bs->view_dev, &bs->view, sizeof(dn::CellDev), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (bs->view_dev) (void)hipFree(bs->view_dev);
+        bs->arena.release(); delete bs;
+        return fail(DN_ERR_HIP, std::string("bias table view: ") + hipGetErrorString(e));
+    }
     m->bias[C] = bs;
     *out = bs;
     return DN_OK;
@@ -418,7 +427,7 @@ int dn_model_create(const float* weights, size_t n_floats, const dn_model_cfg* c
 
 static void model_release(dn_model* m) {
     if (!m || m->refs.fetch_sub(1) != 1) return;
-    for (auto& kv : m->bias) { kv.second->arena.release(); delete kv.second; }
+    for (auto& kv : m->bias) { kv.second->arena.release(); if (kv.second->view_dev) (void)hipFree(kv.second->view_dev); delete kv.second; }
     m->packed.release();
     delete m;
 }
@@ -663,6 +672,13 @@ int dn_dsp_create(const dn_dsp_cfg* cfg, const float* fb_in, const float* pinv_i
     v.pinv_t = M ? d->arena.ptr<float>(o_pinv) : nullptr;
     v.ginv_band = has_factors ? d->arena.ptr<float>(o_ginv) : nullptr;
     v.fb2 = has_factors ? d->arena.ptr<float4>(o_fb2) : nullptr;
+    e = hipMalloc(reinterpret_cast<void**>(&d->view_dev), sizeof(dn::DspDev));
+    if (e == hipSuccess) e = hipMemcpy(d->view_dev, &d->view, sizeof(dn::DspDev), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (d->view_dev) (void)hipFree(d->view_dev);
+        d->arena.release(); delete d;
+        return fail(DN_ERR_HIP, std::string("plan view: ") + hipGetErrorString(e));
+    }
     *out = d;
     return DN_OK;
 }
@@ -670,6 +686,7 @@ int dn_dsp_create(const dn_dsp_cfg* cfg, const float* fb_in, const float* pinv_i
 static void dsp_release(dn_dsp* d) {
     if (!d || d->refs.fetch_sub(1) != 1) return;
     d->arena.release();
+    if (d->view_dev) (void)hipFree(d->view_dev);
     delete d;
 }
 
@@ -1146,6 +1163,7 @@ static int fill_hop_args(dn_pipe* p, dn::HopArgs& a, const float* init_angles, u
     if (p->group > 0) {          // whole chains (group_kernel): a workgroup's four wavefronts = spb streams x the pending frames of each
         a.glw = 1; a.depth = 1; a.split = 0; a.gl_split = 0;
         a.spb = p->group == 1 ? 4 : p->group == 2 ? 2 : 1;
+        a.n_mels = p->d->cfg.n_mels; a.d_dev = p->d->view_dev; a.c_dev = p->bs->view_dev;
         a.back_blocks = (p->B + a.spb - 1) / a.spb;
     }
     return DN_OK;

@@ -28,7 +28,7 @@ static __device__ unsigned long long g_group_wg[2048][2];
 #endif
 
 template <int NFFT, bool STREAM, bool BF16, int CT>
-__global__ __launch_bounds__(kHopPipeThreads, 2) void group_kernel(DspDev d, CellDev cd, HopArgs a) {
+__global__ __launch_bounds__(kHopPipeThreads, 2) void group_kernel(DspDev d, const DspDev* __restrict__ dp, const CellDev* __restrict__ cp, HopArgs a) {
     // n_fft 1024 only.  At 1536 a chain wave needs the state of three columns of 768 complex values: 420 registers.  Built in round 4 as a split group
     // (the chains as a launch of their own, one wave a SIMD, nothing spilled; the front halves as a second launch) and measured SLOWER than the one-hop
     // pipe's wavefront per column: 118.6 against 95.8 us per batch-256 hop, 443 against 370 us at 1,024 streams -- one wave runs six 768-point
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(kHopPipeThreads, 2) void group_kernel(DspDev d, Cel
     const int tid = threadIdx.x;
     const unsigned long long pushes = a.ctl->pushes, frames = a.ctl->frames;
     const unsigned int pending = a.ctl->pending, slot_next = a.ctl->slot_next;
-    const SlotLayout sl(a.B, d.n_mels, kBins);
+    const SlotLayout sl(a.B, a.n_mels, kBins);
     // new hops that only fill the ring (the first n_fft / hop - 1 pushes of a stream, app3.py:174-178), the others are fronted
     int prime_hops = 0;
     if (STREAM) {
@@ -137,8 +137,8 @@ __global__ __launch_bounds__(kHopPipeThreads, 2) void group_kernel(DspDev d, Cel
             // needs it, as in the single-hop kernels.
             int z;
             DN_OPAQUE_ZERO(z);
-            const DspDev dz = rebase(d, z);
-            const CellDev cz = rebase(cd, z);
+            const DspDev& dz = dp[z];
+            const CellDev& cz = cp[z];
             const int tidz = tid + z;
             const float* frames_in = STREAM ? a.ring : a.frames + (size_t)h * (size_t)a.frames_stride;
             if (STREAM) {
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(kHopPipeThreads, 2) void group_kernel(DspDev d, Cel
 void launch_group(const DspDev& d, const CellDev& c, const HopArgs& a, bool bf16, hipStream_t st) {
     const dim3 grid(a.back_blocks + a.front_B), block(kHopPipeThreads);
     const bool stream = a.ola != nullptr, usual = a.C == 5;
-    auto go = [&](auto k) { hipLaunchKernelGGL(k, grid, block, 0, st, d, c, a); };
+    auto go = [&](auto k) { hipLaunchKernelGGL(k, grid, block, 0, st, d, a.d_dev, a.c_dev, a); };
     if (stream) {
         if (usual) { if (bf16) go(group_kernel<1024, true, true, 5>); else go(group_kernel<1024, true, false, 5>); }
         else { if (bf16) go(group_kernel<1024, true, true, 0>); else go(group_kernel<1024, true, false, 0>); }

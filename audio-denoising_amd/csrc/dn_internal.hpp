@@ -181,7 +181,8 @@ struct HopArgs {
     // takes its injected phases from init_in + h * init_in_stride and is written to gl_out + h * out_stride; a streaming launch emits `group_out`
     // hops at hop_out + i * hop_out_stride (strides in elements of the respective type); filler_first: hops without a frame behind them (start of a
     // stream) are the leading ones of a push and the trailing ones of a flush
-    int group_hops, group_out, filler_first;
+    int group_hops, group_out, filler_first, n_mels;
+    const DspDev* d_dev; const CellDev* c_dev;          // device copies of the plan's and the model's views (group_kernel reads them where it needs them)
     long long frames_stride, out_stride, init_in_stride, hop_in_stride, hop_out_stride;
 };
 void launch_host_copy(const uint4* src, uint4* dst, unsigned int n16, unsigned long long* done, unsigned long long value, hipStream_t st);
