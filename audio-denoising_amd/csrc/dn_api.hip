@@ -959,6 +959,7 @@ void dn_pipe_destroy(dn_pipe* p) {
 int dn_pipe_set_head_start(dn_pipe* p, int32_t iterations) {
     if (!p || iterations < 0) return fail(DN_ERR_INVALID, "dn_pipe_set_head_start: bad argument");
     if (iterations > 0 && p->group > 0) return fail(DN_ERR_INVALID, "dn_pipe_set_head_start: a group pipe never parks a chain");
+    if (iterations > 0 && p->split == DN_SPLIT_ON) return fail(DN_ERR_INVALID, "dn_pipe_set_head_start: the pipe splits every hop into two launches (dn_pipe_set_split(p, DN_SPLIT_OFF or DN_SPLIT_AUTO) first)");
     if (iterations > 0 && !p->gl_state) DN_HIP(hipMalloc(reinterpret_cast<void**>(&p->gl_state), p->n_slots * p->state_elems * sizeof(float2)));
     if (iterations > 0 && p->d->cfg.n_fft == 1536) {      // n_fft 1536: the front workgroup's spare wave draws the head start's initial phases into the slot
         int rc = dn_pipe_reserve_parity(p);
@@ -1057,6 +1058,10 @@ int dn_pipe_set_split(dn_pipe* p, int32_t mode) {
     if (mode != DN_SPLIT_AUTO && mode != DN_SPLIT_OFF && mode != DN_SPLIT_ON) return fail(DN_ERR_INVALID, "dn_pipe_set_split: unknown mode");
     if (mode == DN_SPLIT_ON && p->d->cfg.n_fft != 1024)
         return fail(DN_ERR_UNSUPPORTED, "the split hop belongs to the wavefront-per-stream Griffin-Lim, which is built for n_fft 1024");
+    if (mode == DN_SPLIT_ON && p->gl_split > 0)
+        return fail(DN_ERR_INVALID, "dn_pipe_set_split: the pipe runs a head start (a front workgroup that goes on with its frame's chain cannot be a launch of its own): "
+                                    "dn_pipe_set_head_start(p, 0) first");
+    if (mode == DN_SPLIT_ON && p->group > 0) return fail(DN_ERR_INVALID, "dn_pipe_set_split: a group pipe is one launch per group");
     p->split = mode;
     return DN_OK;
 }
@@ -1269,7 +1274,8 @@ int dn_pipe_stream_push_host(dn_pipe* p, const void* hop_in_host, int32_t in_is_
             p->host_copy_src = nullptr; p->host_copy_dst = nullptr; p->host_copy_bytes = 0;
             if (rc != DN_OK) return rc;
             h->defer_pending = defer;
-            if (defer) { h->defer_ticket = h->pushes; h->defer_dst = dout; h->defer_bytes = out_bytes; h->defer_stream = cs; }
+            h->defer_stream = cs;                                  // (also what dn_pipe_stream_host_wait polls for errors)
+            if (defer) { h->defer_ticket = h->pushes; h->defer_dst = dout; h->defer_bytes = out_bytes; }
             h->last_zero_copy[h->pushes % HostIo::kRing] = true;
             if (ticket) *ticket = h->pushes;
             ++h->pushes;
@@ -1310,19 +1316,46 @@ int dn_pipe_stream_host_wait(dn_pipe* p, uint64_t ticket) {
         int rc = host_defer_drain(h, h->defer_stream);
         if (rc != DN_OK) return rc;
     }
-    // the last kRing pushes still own their events; the download queue is in order, so for an older push the oldest event still alive will do
-    const uint64_t oldest = h->pushes > (uint64_t)HostIo::kRing ? h->pushes - HostIo::kRing : 0;
-    const uint64_t e = ticket > oldest ? ticket : oldest;
-    if (h->last_zero_copy[e % HostIo::kRing]) {
-        // launches of one stream complete in order: the word only grows.  Spin briefly, then yield (a hop is tens of microseconds)
-        const volatile unsigned long long* w = h->done_host;
-        for (unsigned spins = 0; __atomic_load_n(w, __ATOMIC_ACQUIRE) < e + 1; ++spins) {
-            if (spins > 2000) std::this_thread::yield();
-            if ((spins & 0xffff) == 0xffff && hipGetLastError() != hipSuccess) return fail(DN_ERR_HIP, "dn_pipe_stream_host_wait: the device reported an error");
+    // Wait for one push by its own transport: a zero-copy push through the completion word its launch (or the launch that carried its deferred
+    // samples out) publishes, a staged one through the event behind its download.
+    auto wait_entry = [&](uint64_t e) -> int {
+        if (h->last_zero_copy[e % HostIo::kRing]) {
+            // launches of one stream complete in order: the word only grows.  Spin briefly, then yield (a hop is tens of microseconds); a launch that
+            // faulted or hangs never publishes, so the stream is polled beside the word: anything but "not ready yet" ends the wait, and "idle" with
+            // the word still short of the ticket (the launches ran, the publication did not) is an error too
+            const volatile unsigned long long* w = h->done_host;
+            for (unsigned spins = 0; __atomic_load_n(w, __ATOMIC_ACQUIRE) < e + 1; ++spins) {
+                if (spins > 2000) std::this_thread::yield();
+                if ((spins & 0x3fff) == 0x3fff) {
+                    const hipError_t q = hipStreamQuery(h->defer_stream);
+                    if (q == hipSuccess) {
+                        if (__atomic_load_n(w, __ATOMIC_ACQUIRE) >= e + 1) break;
+                        return fail(DN_ERR_HIP, "dn_pipe_stream_host_wait: the stream is idle but push " + std::to_string(e) + " was never published");
+                    }
+                    (void)hipGetLastError();          // (hipErrorNotReady is sticky in the thread's last-error slot)
+                    if (q != hipErrorNotReady) return fail(DN_ERR_HIP, std::string("dn_pipe_stream_host_wait: ") + hipGetErrorString(q));
+                }
+            }
+            return DN_OK;
         }
+        DN_HIP(hipEventSynchronize(h->ev_d2h[e % HostIo::kRing]));
         return DN_OK;
+    };
+    // Only the last kRing pushes still own their events and their transport flag.  Either transport completes in order, so an older ticket is
+    // complete once the OLDEST surviving push of EACH transport is -- and where the ring holds no staged push any more, once the download queue has
+    // drained (a zero-copy launch says nothing about a download on another queue; a staged push does cover the zero-copy launches before it: its
+    // download follows its own launch on the caller's stream).
+    const uint64_t oldest = h->pushes > (uint64_t)HostIo::kRing ? h->pushes - HostIo::kRing : 0;
+    if (ticket >= oldest) return wait_entry(ticket);
+    bool seen[2] = {false, false};
+    for (uint64_t e = oldest; e < h->pushes; ++e) {
+        const int kind = h->last_zero_copy[e % HostIo::kRing] ? 1 : 0;
+        if (seen[kind]) continue;
+        seen[kind] = true;
+        int rc = wait_entry(e);
+        if (rc != DN_OK) return rc;
     }
-    DN_HIP(hipEventSynchronize(h->ev_d2h[e % HostIo::kRing]));
+    if (!seen[0] && h->d2h) DN_HIP(hipStreamSynchronize(h->d2h));
     return DN_OK;
 }
 

@@ -542,7 +542,11 @@ class _Queues:
                 pipe.set_depth(depth)
             elif denoiser.n_fft == 1024:
                 pipe.set_gl_schedule(_lib.DN_GL_WAVE_PER_STREAM)                 # (what a split hop needs)
-            pipe.set_split(_lib.DN_SPLIT_ON if split and denoiser.n_fft == 1024 else _lib.DN_SPLIT_OFF)
+            if split and denoiser.n_fft == 1024:
+                pipe.set_head_start(0)          # (a front workgroup that is a launch of its own cannot go on with its frame's chain: the library refuses the combination)
+                pipe.set_split(_lib.DN_SPLIT_ON)
+            else:
+                pipe.set_split(_lib.DN_SPLIT_OFF)
             self.pipes.append(pipe)
 
     def _each(self):

@@ -59,6 +59,8 @@ constexpr unsigned hipStreamNonBlocking = 1, hipEventDisableTiming = 2;
 inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return 0; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+constexpr hipError_t hipErrorNotReady = 600;
+inline hipError_t hipStreamQuery(hipStream_t) { return 0; }          // (launches run to completion inside the launch call)
 inline hipError_t hipDeviceSynchronize() { return 0; }
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
 inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return 0; }

@@ -1410,6 +1410,14 @@ def test_hop_groups_refuse_what_they_do_not_run_and_replay_under_a_graph(dev):
         pipe.submit_group(f, dn.init_hx(4), torch.empty_like(f))
     with pytest.raises(DnError, match="overlap"):
         pipe.lib.check(pipe.lib.dn_pipe_submit_group(pipe.handle, f.data_ptr(), 0, dn.init_hx(4).data_ptr(), f.data_ptr(), 0, None, 0, 0, 0, 2, 32, 0.99, None))
+    hs = HopPipeline(dn, 4)              # (up to 256 streams a one-hop pipe runs a head start: a split hop cannot)
+    with pytest.raises(DnError, match="head start"):
+        hs.set_split(1)
+    hs.set_head_start(0)
+    hs.set_gl_schedule(2)
+    hs.set_split(1)
+    with pytest.raises(DnError, match="splits every hop"):
+        hs.set_head_start(3)
     ps = PipelinedStream(dn, 4)
     ps.set_group(2)
     with pytest.raises(DnError, match="groups of hops"):
