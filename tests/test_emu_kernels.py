@@ -656,18 +656,19 @@ def test_hop_groups_run_whole_chains_bit_identically(lib, dsp, H):
     m = make_model(lib, 5)
     rg = np.random.default_rng(23)
     init = [emu.f32(rg.random((B, 3, P.n_stft, 2))) for _ in range(n_hops)]
-    for kw in (dict(init=None), dict(init=init)):
-        a = _run_pipe(lib, dsp, m, DN_GL_WAVE_PER_COLUMN, B, n_hops, g, n_iter=4, **kw)
-        for sizes in (None, [1, H, 1, H]):
-            b = _run_groups(lib, dsp, m, B, n_hops, g, H, sizes=sizes, n_iter=4, **kw)
-            assert len(a) == len(b)
-            for x, y in zip(a, b):
-                assert np.array_equal(x, y)
-        assert np.abs(a[0]).max() > 0
+    # (the emulator runs a work-item per OS thread: H = 2 takes the device-RNG phases and full groups -- two streams a chain workgroup --, H = 4 the
+    # injected phases and uneven submits; the gpu tier runs every combination at batch 256 and 32 iterations)
+    kw, sizes = (dict(init=None), None) if H == 2 else (dict(init=init), [1, H, 1, H])
+    a = _run_pipe(lib, dsp, m, DN_GL_WAVE_PER_COLUMN, B, n_hops, g, n_iter=4, **kw)
+    b = _run_groups(lib, dsp, m, B, n_hops, g, H, sizes=sizes, n_iter=4, **kw)
+    assert len(a) == len(b)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    assert np.abs(a[0]).max() > 0
     lib.dn_model_destroy(m)
 
 
-@pytest.mark.parametrize("s16", [False, True])
+@pytest.mark.parametrize("s16", [True])
 def test_streaming_hop_groups_emit_the_one_hop_pipes_samples_later(lib, dsp, s16):
     """dn_pipe_stream_push_group: H hops in, H hops out per launch; the chains of one stream finish in the same launch and fold into its
     overlap-add line IN ORDER.  The emitted stream is the one-hop pipe's, H - 1 hops later (zeros first); ring, overlap-add line and hx after the

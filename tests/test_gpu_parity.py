@@ -889,6 +889,10 @@ def test_c_abi_host_without_python_gives_the_same_samples(dev, tmp_path):
         dn.process_frame_(torch.from_numpy(h).to(dev), hx, out, seed=2024 + hop, stream_id0=0)
     torch.cuda.synchronize()
     assert np.array_equal(got, out.cpu().numpy())
+    # the same hops in groups of two per launch (dn_pipe_set_group / dn_pipe_submit_group through the C ABI): the same bits again
+    r = subprocess.run([exe, os.path.join(GOLDEN, "weights_dari_tult.bin"), outf, str(B), str(hops), "2"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert np.array_equal(np.fromfile(outf, dtype=np.float32).reshape(B, 1024), got)
 
 
 def test_bench_two_ranks_on_one_gpu(dev):
