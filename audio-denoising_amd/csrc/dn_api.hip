@@ -1113,6 +1113,8 @@ int dn_pipe_stream_set_state(dn_pipe* p, const float* ring, const float* ola, co
     int rc = stream_state_copy(p, const_cast<float*>(ring), const_cast<float*>(ola), const_cast<float*>(hx), true, stream);
     if (rc != DN_OK) return rc;
     // a restored ring is a primed ring; a hop that was pending is dropped (flush before taking a snapshot)
+    p->group_pushes = (unsigned long long)(p->d->cfg.n_fft / p->d->cfg.hop - 1);          // (the host's own bookkeeping of a group pipe: primed, nothing pending)
+    p->group_pending = 0;
     dn::launch_ctl_set(p->ctl, (unsigned long long)(p->d->cfg.n_fft / p->d->cfg.hop - 1), frames_done, 0, as_stream(stream));
     return check_launch("ctl_set_kernel");
 }

@@ -10,8 +10,9 @@ namespace dn {
 // long as a chain: it carries H consecutive new hops of every stream -- their front halves one after the other in the stream's front workgroup,
 // hx handed from hop to hop -- beside the WHOLE chains of the H hops the previous launch fronted, one wavefront each.  A chain is never cut, nothing
 // is parked, a frame's phases are drawn by its own chain wave; between launches only the slots travel (magnitudes, peak, meta: 6.5 KB a frame).
-//   blocks [0, back_B)           stream b's pending frames: wavefront j runs the chain of the j-th oldest one from its first iteration to its last
-//   blocks [back_B, back_B + B)  P1-P10 of stream b's `group_hops` new hops, in order, into slots slot_next, slot_next + 1, ...
+//   blocks [0, back_blocks)            the pending frames of spb = 4 / H streams: wavefront w runs the chain of the (w % per)-th oldest frame of stream
+//                                      blockIdx.x * spb + w / per (per = 4 / spb) from its first iteration to its last
+//   blocks [back_blocks, back_blocks + B)  P1-P10 of stream b's `group_hops` new hops, in order, into slots slot_next, slot_next + 1, ...
 // Same arithmetic, same seeds (seed + frame index, stream id), same slots as the one-hop pipe: frames, hx and emitted hops are bit-identical to it.
 // The price is granularity, not latency: input arrives H hops at a time and a frame is complete one launch (H hops) after its group was submitted.
 #ifdef DN_PROBE

@@ -1359,6 +1359,31 @@ def test_hop_groups_are_bit_identical_to_the_one_hop_pipe_at_batch_256(dev, H):
     assert torch.equal(ring_a, ring_b) and torch.equal(ola_a, ola_b) and torch.equal(hx_a, hx_b)
 
 
+@pytest.mark.parametrize("tag,conv", [("R2", "fp32"), ("S", "bf16")])
+def test_hop_groups_other_instantiations_equal_the_one_hop_pipe(dev, tag, conv):
+    """The group kernel's other instantiations: 64 mels (server.py's parameters: four compressed bins, run-time lengths in the model stage) and the
+    bf16 conv tiles of config 3 -- frames and hx equal the one-hop pipe of the same precision bit for bit (groups of three: a short last group)."""
+    from audio_denoising_amd.pipeline import Denoiser, HopPipeline
+    p = _params(tag)
+    m = _model(dev, p.num_compressed_bins)
+    m.conv_precision = conv
+    dn = Denoiser(m, p.sample_rate, p.n_fft, p.hop, p.n_mels)
+    B, n, H = 40, 5, 3
+    frames = (0.1 * torch.randn(n, B, p.n_fft, generator=torch.Generator().manual_seed(77))).to(dev)
+    one, grp = HopPipeline(dn, B), HopPipeline(dn, B)
+    grp.set_group(H)
+    hx_a, hx_b = dn.init_hx(B), dn.init_hx(B)
+    out_a, out_b = torch.empty_like(frames), torch.empty_like(frames)
+    for i in range(n):
+        one.submit(frames[i], hx_a, out_a[i], seed=5, stream_id0=2)
+    one.flush()
+    for i in range(0, n, H):
+        grp.submit_group(frames[i:i + H], hx_b, out_b[i:i + H], seed=5, stream_id0=2)
+    grp.flush()
+    torch.cuda.synchronize()
+    assert torch.equal(hx_a, hx_b) and torch.equal(out_a, out_b) and torch.isfinite(out_a).all() and out_a.abs().max().item() > 0
+
+
 def test_hop_groups_at_batch_256_directly_against_the_oracle(dev):
     """The configuration the bench times since round 4 (groups of four hops, whole chains), compared with the oracle DIRECTLY: batch 256, two
     groups (eight chained hops) with injected Griffin-Lim phases, every stream: waveform at the batch-256 guard bands and the carried hx."""
