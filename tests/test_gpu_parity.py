@@ -1386,7 +1386,9 @@ def test_hop_groups_other_instantiations_equal_the_one_hop_pipe(dev, tag, conv):
 
 def test_hop_groups_at_batch_256_directly_against_the_oracle(dev):
     """The configuration the bench times since round 4 (groups of four hops, whole chains), compared with the oracle DIRECTLY: batch 256, two
-    groups (eight chained hops) with injected Griffin-Lim phases, every stream: waveform at the batch-256 guard bands and the carried hx."""
+    groups (five chained hops: a full group and a short one) with injected Griffin-Lim phases; every fourth stream of the 256 (the CPU oracle takes
+    ~0.1 s per stream and hop; all 256 streams of this schedule are compared bit for bit with the one-hop pipe, which IS compared with the oracle
+    on all of them): waveform at the batch-256 guard bands and the carried hx."""
     from audio_denoising_amd.pipeline import Denoiser, HopPipeline
     from oracle import dsp_ref, pipeline_ref
     p = pipeline_ref.PARAMS_S
@@ -1405,15 +1407,17 @@ def test_hop_groups_at_batch_256_directly_against_the_oracle(dev):
     torch.cuda.synchronize()
     fb = dsp_ref.melscale_fbanks(p.n_stft, p.n_mels, p.sample_rate)
     sd = _state_dict("dari_tult")
-    h = torch.zeros(256, 17, 5)
+    idx = torch.arange(1, 256, 4)
+    h = torch.zeros(len(idx), 17, 5)
     with torch.no_grad():
         for i in range(n):
-            ref = pipeline_ref.process_frame(sd, hops[i], h, p, fb, init_angles=inits[i])
+            ref = pipeline_ref.process_frame(sd, hops[i][idx], h, p, fb, init_angles=inits[i][idx])
             h = ref["hx"]
-            rms, mx = _wave_close(out[i].cpu().numpy(), ref["out"].numpy())
-            per_stream = (out[i].cpu() - ref["out"]).pow(2).mean(dim=1).sqrt().numpy()
+            got = out[i].cpu()[idx]
+            rms, mx = _wave_close(got.numpy(), ref["out"].numpy())
+            per_stream = (got - ref["out"]).pow(2).mean(dim=1).sqrt().numpy()
             assert rms <= GUARD_B256_WAVE_RMS and mx <= GUARD_B256_WAVE_MAX and np.median(per_stream) <= GUARD_B256_STREAM_MEDIAN_RMS, (i, rms, mx)
-    assert (hx.cpu() - h).abs().max().item() <= GUARD_HX
+    assert (hx.cpu()[idx] - h).abs().max().item() <= GUARD_HX
 
 
 def test_hop_groups_refuse_what_they_do_not_run_and_replay_under_a_graph(dev):
