@@ -72,6 +72,9 @@ __global__ __launch_bounds__(kHopPipeThreads, 2) void group_kernel(DspDev d, con
             const int n_iter = __builtin_amdgcn_readfirstlane((int)meta[6]);
             const float mom = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane((int)meta[7]));
             float* gl_out = reinterpret_cast<float*>((uint64_t)meta[8] | ((uint64_t)meta[9] << 32));
+#ifdef DN_GLW_PRIO
+            __builtin_amdgcn_s_setprio(DN_GLW_PRIO);          // (experiment knob: measured below)
+#endif
             glw_body<NFFT, STREAM ? kEmitStage : kEmitFrame>(smem, d, slot + sl.lin, init, seed, sid0, slot + sl.peak, gl_out, n_iter, mom, b, lane, wv,
                                                              nullptr, nullptr, 0, 0, -1, kGlwFresh, nullptr, tid);
             DN_WSTAMP(7);
