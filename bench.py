@@ -914,7 +914,11 @@ def main():
             "roofline": {"bound": "fp32-valu", "bound_detail": "fp32 vector ALU (FFT butterflies, 78 % of the flops) + fp32 MFMA (convs): the fp32 compute roof, "
                                                                "157.3 TFLOP/s either way; not HBM (hbm_frac) and not the matrix pipe",
                          "kernel": dom_name, "achieved": round(ach, 3), "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ach / PEAK_FP32_TFLOPS, 4), "traffic": traffic, "note": dom_note,
+                         "frac": round(ach / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
+                         "traffic_source": None if traffic is None else "profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes taken by "
+                                                                        "tools/collect_profiles.sh beside the committed kernel statistics (2 x FETCH + WRITE, per launch); "
+                                                                        "counters cannot be read from inside this process, so this is NOT a measurement of this run",
+                         "note": dom_note,
                          "launch_ms": round(dom_ms, 4), "hops_per_launch": per_launch, "ms_per_hop": round(dom_ms / per_launch, 4),
                          "algorithmic_bytes_per_launch": HBM_BYTES_PER_FRAME * B * per_launch,
                          "hbm_frac": round(HBM_BYTES_PER_FRAME * B * per_launch / gl_s / 1e9 / PEAK_HBM_GBS, 6)},
