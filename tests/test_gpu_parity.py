@@ -1384,6 +1384,48 @@ def test_hop_groups_other_instantiations_equal_the_one_hop_pipe(dev, tag, conv):
     assert torch.equal(hx_a, hx_b) and torch.equal(out_a, out_b) and torch.isfinite(out_a).all() and out_a.abs().max().item() > 0
 
 
+@pytest.mark.parametrize("batch,H", [(1, 4), (3, 2), (17, 1), (255, 2), (257, 4), (1001, 1), (1001, 2)])
+def test_hop_groups_at_odd_batch_sizes_equal_the_one_hop_pipe(dev, batch, H):
+    """Batch sizes that are no multiple of the streams a chain workgroup holds (4 / H): a last workgroup with idle wavefronts, a single stream, more
+    streams than CUs.  Frames, hx and -- streaming, int16 -- the emitted samples and the stream state equal the one-hop pipe bit for bit."""
+    from audio_denoising_amd.pipeline import Denoiser, HopPipeline, PipelinedStream
+    p = _params("S")
+    dn = Denoiser(_model(dev, 5), p.sample_rate, p.n_fft, p.hop, p.n_mels)
+    g = torch.Generator().manual_seed(31 * batch + H)
+    n = 2 * H + 1
+    frames = (0.1 * torch.randn(n, batch, p.n_fft, generator=g)).to(dev)
+    one, grp = HopPipeline(dn, batch), HopPipeline(dn, batch)
+    grp.set_group(H)
+    hx_a, hx_b = dn.init_hx(batch), dn.init_hx(batch)
+    out_a, out_b = torch.empty_like(frames), torch.empty_like(frames)
+    for i in range(n):
+        one.submit(frames[i], hx_a, out_a[i], seed=3, stream_id0=11)
+    one.flush()
+    for i in range(0, n, H):
+        grp.submit_group(frames[i:i + H], hx_b, out_b[i:i + H], seed=3, stream_id0=11)
+    grp.flush()
+    torch.cuda.synchronize()
+    assert torch.equal(hx_a, hx_b) and torch.equal(out_a, out_b) and torch.isfinite(out_a).all() and out_a.abs().max().item() > 0
+    n_push = 4 * H          # (the first push primes the ring and a hop is emitted a push after its frame was folded: enough pushes for samples to come out)
+    pcm = ((0.3 * torch.randn(batch, n_push * p.hop, generator=g)).clamp(-1, 1) * 32767.0).to(torch.int16).to(dev)
+    ps = PipelinedStream(dn, batch, seed=3, stream_id0=40)
+    ea = torch.cat([ps.push(pcm[:, i * p.hop:(i + 1) * p.hop].contiguous()) for i in range(n_push)] + [ps.flush(s16=True)], 1)
+    st_a = ps.state()
+    pg = PipelinedStream(dn, batch, seed=3, stream_id0=40)
+    pg.set_group(H)
+    o = []
+    for i in range(0, n_push, H):
+        o += list(pg.push_group(torch.stack([pcm[:, j * p.hop:(j + 1) * p.hop] for j in range(i, i + H)]).contiguous()))
+    tail, valid = pg.flush_group(s16=True)
+    st_b = pg.state()
+    torch.cuda.synchronize()
+    eb = torch.cat(o + list(tail), 1)
+    lag = (H - 1) * p.hop
+    assert torch.equal(eb[:, lag:lag + ea.shape[1]], ea) and not eb[:, :lag].any() and ea.abs().max().item() > 0
+    for x, y in zip(st_a[:3], st_b[:3]):
+        assert torch.equal(x, y)
+
+
 def test_hop_groups_at_batch_256_directly_against_the_oracle(dev):
     """The configuration the bench times since round 4 (groups of four hops, whole chains), compared with the oracle DIRECTLY: batch 256, two
     groups (five chained hops: a full group and a short one) with injected Griffin-Lim phases; every fourth stream of the 256 (the CPU oracle takes
