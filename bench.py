@@ -706,7 +706,10 @@ def main():
         torch.cuda.set_device(dev)
     dist = None
     ranks_seen = 1
-    if world > 1:
+    # DN_BENCH_FORCE_DIST=1: a ONE-rank job (under a launcher) still builds its process group and runs every collective call of the multi-rank path --
+    # how the RCCL branch (init with device_id, all_reduce, barrier with device_ids, the ingress loop's calls) is exercised on a one-GPU box
+    force_dist = os.environ.get("DN_BENCH_FORCE_DIST") == "1" and "WORLD_SIZE" in os.environ
+    if world > 1 or force_dist:
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -802,7 +805,7 @@ def main():
         print(f"[bench] {args.steps} steps x {B * world} frames in {elapsed:.4f} s", file=sys.stderr, flush=True)
 
     ingress = None
-    if world > 1 and pipe is not None:
+    if (world > 1 or force_dist) and pipe is not None:
         # a side measurement must never cost the headline line: any failure in it (on every rank alike: the loop is collective) is reported, not raised
         try:
             # the headline's schedule: one launch = `group` hops (its double buffering needs only that launch i completes the unit launch i-1 fronted)
@@ -839,7 +842,7 @@ def main():
         if ingress is not None:
             line["ingress_variant"] = ingress
             line["ingress_ok"] = "error" not in ingress and bool(ingress.get("root_output_finite", False))
-        line["ranks"] = {"seen": ranks_seen, "backend": backend if world > 1 else None,
+        line["ranks"] = {"seen": ranks_seen, "backend": backend if (world > 1 or force_dist) else None,
                          "rank0_device": (torch.cuda.get_device_name(dev) if on_gpu else "cpu"), "local_rank": local}
     if rank == 0 and on_gpu:
         # the same K steps strictly one after another, nothing overlapped (dn_process_frame: one launch, no added hop of latency)

@@ -915,6 +915,34 @@ def test_bench_two_ranks_on_one_gpu(dev):
     assert d["roofline"]["frac"] > 0 and d["value"] > 0
 
 
+def test_bench_one_rank_over_rccl_runs_every_collective_call(dev):
+    """The RCCL branch of bench.py on this one-GPU box: ONE rank under torch.distributed.run with the `nccl` backend (DN_BENCH_FORCE_DIST=1 keeps the
+    process group although the world is 1): init_process_group(device_id=...), the rank-count all_reduce, barrier(device_ids=...), the MAX reduction of
+    the timing and the ingress loop's scatter_rows / gather_rows calls on a second HIP stream -- everything the multi-GPU run executes except a
+    transfer between two devices, which needs the driver's node (RCCL refuses two ranks on one device)."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    from conftest import REPO
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, DN_DIST_BACKEND="nccl", DN_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "8", "--warmup", "4", "--no-cpu-baseline", "--no-extras"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=REPO)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["ranks_seen"] == 1 and d["ranks"]["backend"] == "nccl" and d["value"] > 0
+    iv = d["ingress_variant"]
+    assert "error" not in iv, iv
+    assert d["ingress_ok"] is True and iv["backend"] == "nccl" and iv["hops_per_launch"] == 4 and iv["root_output_finite"] is True
+
+
 def test_real_clip_3s_batch1_streams_match_oracle_golden(dev):
     """BASELINE configs[0] at its stated size: ONE 3 s / 16 kHz clip (93 hops, batch 1, dari_tult weights) of real audio from the
     reference's data tree (tests/golden/clip_S.npz, made by oracle/make_clip_golden.py), streamed hop by hop as the app's recv()
