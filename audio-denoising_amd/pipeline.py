@@ -631,7 +631,7 @@ def throughput_plan(batch: int, n_fft: int = 1024) -> dict:
     ``QueuedHopPipelines``.  Every choice gives the same samples; what changes is how many hops lie between handing a hop over and its output.
     ``group`` > 0: input that can be handed over ``group`` hops at a time goes through hop groups (``submit_group``: whole Griffin-Lim chains
     per launch, nothing parked); ``depth`` is what a caller that submits hop by hop gets instead.
-      up to 384 streams    one pipe; groups of four hops (batch 256: 40.0 us per hop) -- hop by hop: four hops in flight (45.8 us; 56.0 at depth 1)
+      up to 384 streams    one pipe; groups of four hops (batch 256: 38.9 us per hop) -- hop by hop: four hops in flight (45.8 us; 56.1 at depth 1)
       385 .. 1,023         one pipe; groups of two hops, two streams a chain workgroup (512 streams: 6.5 M frames/s) -- hop by hop: depth 2 (6.1 M)
       1,024 .. 2,047       two pipes on two HIP streams, split hops, two hops in flight (1,024 streams: 7.6 M frames/s against 6.7 M)
       2,048 and up         an even number of pipes of about 1,024 streams, taking turns on two HIP streams, split hops, one hop in flight
