@@ -19,5 +19,8 @@ Pinning status
   reference has no tests or fixtures for these stages.  ``dsp_ref`` restates
   torchaudio's published semantics over first-party ``torch.stft`` /
   ``torch.istft`` / ``torch.linalg.lstsq``; ``dsp_np64`` is an independent
-  float64 numpy implementation written separately (double-entry check).
+  float64 numpy implementation written separately (double-entry check); scipy.signal / scipy.linalg and
+  HuggingFace ``transformers.audio_utils`` (mel filterbank, STFT) are further opinions (tests/test_oracle_dsp.py).
+  ``pipeline_np64`` evaluates the whole hop in float64 on the fp32 constants: the yardstick that tells
+  rounding from error (tests/golden/metric_f64_B256.npz, its model stage run by the reference's own class in double).
 """

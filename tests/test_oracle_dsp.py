@@ -166,3 +166,21 @@ def test_third_opinion_griffinlim_inner_step_and_min_norm_inverse_mel(p):
         assert rank == p.n_mels
         assert np.abs(np.maximum(sol, 0.0) - ours[b]).max() <= 2e-4
         assert np.abs(sol - sl.pinv(A) @ mel[b].numpy().astype(np.float64)).max() <= 1e-8
+
+
+def test_filterbank_and_stft_agree_with_a_fourth_independent_implementation():
+    """HuggingFace `transformers.audio_utils` (installed here, unrelated to this repo and to torchaudio's code base) documents its `mel_filter_bank(norm=None,
+    mel_scale="htk")` and `spectrogram(center=True, pad_mode="reflect")` as equivalents of torchaudio's / librosa's: the oracle's restatement of
+    `melscale_fbanks` (app3.py:139-148) agrees with it to fp32 rounding of the fp32 formula at all three parameter sets, the 3-column STFT of a frame
+    (app3.py:191) to 2e-7 relative.  Still not a pin to the reference's torchaudio==2.6.0 -- a fourth opinion on what its published algorithm is."""
+    au = pytest.importorskip("transformers.audio_utils")
+    for p in (pipeline_ref.PARAMS_S, pipeline_ref.PARAMS_R1, pipeline_ref.PARAMS_R2):
+        fb = dsp_ref.melscale_fbanks(p.n_stft, p.n_mels, p.sample_rate).numpy()
+        other = au.mel_filter_bank(num_frequency_bins=p.n_stft, num_mel_filters=p.n_mels, min_frequency=0.0, max_frequency=float(p.sample_rate // 2),
+                                   sampling_rate=p.sample_rate, norm=None, mel_scale="htk")
+        assert other.shape == fb.shape and np.abs(fb - other).max() <= 1e-5
+        x = (0.1 * torch.randn(p.n_fft, generator=torch.Generator().manual_seed(3))).numpy().astype(np.float64)
+        s = au.spectrogram(x, au.window_function(p.n_fft, "hann", periodic=True), frame_length=p.n_fft, hop_length=p.hop, fft_length=p.n_fft, power=None,
+                           center=True, pad_mode="reflect", onesided=True)
+        ref = dsp_ref.spectrogram(torch.from_numpy(x).float()[None], p.n_fft, p.hop).numpy()[0]
+        assert s.shape == ref.shape == (p.n_stft, 3) and np.abs(s - ref).max() <= 5e-7 * np.abs(ref).max()
