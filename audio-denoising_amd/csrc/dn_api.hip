@@ -1167,10 +1167,10 @@ static int fill_hop_args(dn_pipe* p, dn::HopArgs& a, const float* init_angles, u
     const bool can_split = per_stream && p->gl_split == 0;
     a.split = can_split && (p->split == DN_SPLIT_ON || (p->split == DN_SPLIT_AUTO && (long)p->B * p->depth >= dn::kSplitAutoChains)) ? 1 : 0;
     a.prime = p->d->cfg.n_fft / p->d->cfg.hop - 1;
+    a.n_mels = p->d->cfg.n_mels; a.d_dev = p->d->view_dev; a.c_dev = p->bs->view_dev;          // (the views in device memory: what the front halves read)
     if (p->group > 0) {          // whole chains (group_kernel): a workgroup's four wavefronts = spb streams x the pending frames of each
         a.glw = 1; a.depth = 1; a.split = 0; a.gl_split = 0;
         a.spb = p->group == 1 ? 4 : p->group == 2 ? 2 : 1;
-        a.n_mels = p->d->cfg.n_mels; a.d_dev = p->d->view_dev; a.c_dev = p->bs->view_dev;
         a.back_blocks = (p->B + a.spb - 1) / a.spb;
     }
     return DN_OK;
