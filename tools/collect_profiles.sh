@@ -54,9 +54,10 @@ done
 batches="256"
 [ -z "$quick" ] && batches="256 1024 8192"
 for b in $batches; do
-  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES SQ_WAIT_ANY -d "$out/pmc_SQ_$b" -o p --output-format csv -- python3 "$root/tools/prof_step.py" 12 $b > "$out/logs/pmc_SQ_$b.log" 2>&1 || die "pmc SQ $b failed"
-  rocprofv3 --pmc SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAVES -d "$out/pmc_SQ2_$b" -o p --output-format csv -- python3 "$root/tools/prof_step.py" 12 $b > "$out/logs/pmc_SQ2_$b.log" 2>&1 || die "pmc SQ2 $b failed"
-  rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_SMEM -d "$out/pmc_SQ3_$b" -o p --output-format csv -- python3 "$root/tools/prof_step.py" 12 $b > "$out/logs/pmc_SQ3_$b.log" 2>&1 || die "pmc SQ3 $b failed"
+  sq_steps=12; [ "$b" = 256 ] && sq_steps=28          # (batch 256: groups of four hops per launch -- enough full launches for the median)
+  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES SQ_WAIT_ANY -d "$out/pmc_SQ_$b" -o p --output-format csv -- python3 "$root/tools/prof_step.py" $sq_steps $b > "$out/logs/pmc_SQ_$b.log" 2>&1 || die "pmc SQ $b failed"
+  rocprofv3 --pmc SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAVES -d "$out/pmc_SQ2_$b" -o p --output-format csv -- python3 "$root/tools/prof_step.py" $sq_steps $b > "$out/logs/pmc_SQ2_$b.log" 2>&1 || die "pmc SQ2 $b failed"
+  rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_INSTS_SMEM -d "$out/pmc_SQ3_$b" -o p --output-format csv -- python3 "$root/tools/prof_step.py" $sq_steps $b > "$out/logs/pmc_SQ3_$b.log" 2>&1 || die "pmc SQ3 $b failed"
   echo pmc $b
 done
 cd "$root"

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 --pmc counter_collection.csv files: mean counter value per kernel per launch.
+"""Summarise rocprofv3 --pmc counter_collection.csv files: MEDIAN counter value per kernel per launch (and the mean beside it).  The median, because
+a run of a pipe holds partial launches -- the first launch of a group pipe carries front halves only, the flush chains only -- and a mean over a
+short run dilutes the full launches with them (round 4's first pass read 24.7 MB / 2.17 M SALU per launch where a full launch moves 27 MB / 2.9 M).
     pmc_summary.py [--traffic-json out.json --kernel substring --frames-per-launch N] csv-glob ...
 --traffic-json: also write profiles/pmc_traffic.json for that kernel from its FETCH_SIZE / WRITE_SIZE means (separate passes), corrected as
 MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE doubled; both counters are in KB."""
@@ -30,8 +32,10 @@ def main():
         print(k)
         means[k] = {}
         for c, v in sorted(cs.items()):
-            means[k][c] = sum(v) / len(v)
-            print(f"   {c:28s} {sum(v) / len(v):16.1f}   (n={len(v)})")
+            w = sorted(v)
+            med = w[len(w) // 2] if len(w) % 2 else 0.5 * (w[len(w) // 2 - 1] + w[len(w) // 2])
+            means[k][c] = med
+            print(f"   {c:28s} {med:16.1f}   (median of n={len(v)}; mean {sum(v) / len(v):.1f})")
     if not means:
         sys.exit("pmc_summary: no dn:: kernel in the counter files")
     if "--traffic-json" in opt:
@@ -45,7 +49,7 @@ def main():
         per_frame = 8872
         total = int((2 * fetch + write) * 1024)
         doc = {
-            "_source": f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) on tools/prof_step.py (batch 256, the bench's schedule); mean per launch of {k}; "
+            "_source": f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) on tools/prof_step.py (batch 256, the bench's schedule); MEDIAN per launch of {k} (a full launch: the run's first launch carries front halves only, its flush chains only); "
                        f"written by tools/collect_profiles.sh {opt.get('--tag', '')}",
             "_unit": "bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 -- FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of wide streaming reads; "
                      "an upper bound for our 8-16 B/lane reads)",
