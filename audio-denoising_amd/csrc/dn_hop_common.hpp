@@ -67,28 +67,12 @@ struct SlotLayout {
     }
 };
 
-// A zero the compiler cannot see through, and the plan's device views rebased by it: loads through the rebased pointers are not loop-invariant, so a
-// loop over large inlined stages (dn_group.hip) does not hoist every table access of every stage above itself.
+// A zero the compiler cannot see through.  dn_group.hip adds it, once per hop, to the pointers through which the front half reads the plan's and the
+// model's views in device memory: loads through a pointer that changes every iteration are not loop-invariant, so a loop over large inlined stages
+// does not hoist every table access of every stage above itself.
 #ifndef DN_OPAQUE_ZERO
 #define DN_OPAQUE_ZERO(z) asm volatile("s_mov_b32 %0, 0" : "=s"(z))
 #endif
-__device__ __forceinline__ DspDev rebase(const DspDev& d, int z) {
-    DspDev r = d;
-    r.twc += z; r.twr += z; r.window += z; r.inv_env += z; r.glw_tables += z; r.mel_start += z; r.mel_len += z; r.mel_w += z; r.mel_q += z;
-    r.pinv_t += z; r.ginv_band += z; r.fb2 += z;
-    return r;
-}
-__device__ __forceinline__ CellDev rebase(const CellDev& c, int z) {
-    CellDev r = c;
-#pragma unroll
-    for (int l = 0; l < 4; ++l) {
-        r.w_down[l] += z; r.w_up[l] += z; r.bt_down[l] += z; r.bt_up[l] += z;
-        r.wb_down[l] = static_cast<const char*>(r.wb_down[l]) + z;
-        if (l < 3) r.wb_up[l] = static_cast<const char*>(r.wb_up[l]) + z;
-    }
-    r.w_gh += z; r.bt_gh += z;
-    return r;
-}
 
 // slot of the frame that is `back` frames behind the next one (slot_next is the slot the next front half writes)
 __device__ __forceinline__ int slot_behind(unsigned int slot_next, int back, int n_slots) {
