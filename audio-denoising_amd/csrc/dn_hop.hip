@@ -19,6 +19,14 @@
 //   advances, so one captured launch replays indefinitely under hipGraph (BASELINE config 5).
 #include "dn_hop_common.hpp"
 
+// The n_fft-1536 instantiations of the kernels below live in a translation unit of their own (dn_hop1536.hip includes this file with DN_HOP_TU_1536):
+// the n_fft-1024 kernels are compiled with LLVM's max-ILP scheduling strategy (Makefile: +1..3 % on the pipes, the unpipelined hop and the saturated
+// regime, profiles/r04_group_sweep.txt), which costs the 1536 ones 12 % (they sit at the 256-register cap and spill more under it).  The stamped
+// diagnostic build keeps everything in this file (its probe arrays are per translation unit).
+#if !defined(DN_PROBE)
+#define DN_HOP_SPLIT_TUS 1
+#endif
+
 namespace dn {
 
 // n_fft 1536: the Griffin-Lim body would take 330 registers and shut the front workgroup out of the CU; capping the
@@ -314,6 +322,7 @@ static void launch_hop_n(const DspDev& d, const CellDev& c, const HopArgs& a, bo
     }
 }
 
+#ifndef DN_HOP_TU_1536
 // a.glw: the caller laid the grid out for a wavefront per stream and chain segment (n_fft 1024 only) instead of a wavefront per column
 // The deferred host output of the LAST push (no further launch will carry it): copy, then publish (dn_pipe_stream_host_wait).
 __global__ void host_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, unsigned int n16) {
@@ -329,6 +338,9 @@ void launch_host_copy(const uint4* src, uint4* dst, unsigned int n16, unsigned l
     hipLaunchKernelGGL(host_publish_kernel, dim3(1), dim3(1), 0, st, done, value);      // (stream order: the copy has completed)
 }
 
+void launch_hop_1536(const DspDev& d, const CellDev& c, const HopArgs& a, bool bf16, hipStream_t st);          // (dn_hop1536.hip)
+void launch_frame_1536(const DspDev& d, const CellDev& c, const FrameArgs& a, int B, bool bf16, hipStream_t st);
+
 void launch_hop(const DspDev& d, const CellDev& c, const HopArgs& a, bool bf16, hipStream_t st) {
     const bool stream = a.ola != nullptr;
     if (a.split && a.glw && a.front_B > 0 && d.n_fft == 1024) {
@@ -342,8 +354,12 @@ void launch_hop(const DspDev& d, const CellDev& c, const HopArgs& a, bool bf16, 
         return;
     }
     if (d.n_fft == 1536) {
+#ifdef DN_HOP_SPLIT_TUS
+        launch_hop_1536(d, c, a, bf16, st);
+#else
         if (stream) launch_hop_n<1536, true, false>(d, c, a, bf16, st);
         else launch_hop_n<1536, false, false>(d, c, a, bf16, st);
+#endif
     } else if (a.glw) {
         if (stream) launch_hop_n<1024, true, true>(d, c, a, bf16, st);
         else launch_hop_n<1024, false, true>(d, c, a, bf16, st);
@@ -361,6 +377,7 @@ __global__ void ctl_set_kernel(PipeCtl* ctl, unsigned long long pushes, unsigned
 void launch_ctl_set(PipeCtl* ctl, unsigned long long pushes, unsigned long long frames, unsigned int pending, hipStream_t st) {
     hipLaunchKernelGGL(ctl_set_kernel, dim3(1), dim3(1), 0, st, ctl, pushes, frames, pending);
 }
+#endif          // DN_HOP_TU_1536
 
 // ---- the unpipelined hop: P1-P12 of one stream in one workgroup, one launch per hop (zero added latency).  Four wavefronts for the
 // front half (the conv phases split four ways), three for the Griffin-Lim chain behind it (the fourth exits).
@@ -399,20 +416,35 @@ static void launch_frame_n(const DspDev& d, const CellDev& c, const FrameArgs& a
     }
 }
 
+#ifndef DN_HOP_TU_1536
 void launch_frame(const DspDev& d, const CellDev& c, const FrameArgs& a, int B, bool bf16, hipStream_t st) {
     const bool stream = a.ring != nullptr;
     if (d.n_fft == 1536) {
+#ifdef DN_HOP_SPLIT_TUS
+        launch_frame_1536(d, c, a, B, bf16, st);
+#else
         if (stream) launch_frame_n<1536, true>(d, c, a, B, bf16, st);
         else launch_frame_n<1536, false>(d, c, a, B, bf16, st);
+#endif
     } else {
         if (stream) launch_frame_n<1024, true>(d, c, a, B, bf16, st);
         else launch_frame_n<1024, false>(d, c, a, B, bf16, st);
     }
 }
+#else          // the n_fft-1536 translation unit
+void launch_hop_1536(const DspDev& d, const CellDev& c, const HopArgs& a, bool bf16, hipStream_t st) {
+    if (a.ola != nullptr) launch_hop_n<1536, true, false>(d, c, a, bf16, st);
+    else launch_hop_n<1536, false, false>(d, c, a, bf16, st);
+}
+void launch_frame_1536(const DspDev& d, const CellDev& c, const FrameArgs& a, int B, bool bf16, hipStream_t st) {
+    if (a.ring != nullptr) launch_frame_n<1536, true>(d, c, a, B, bf16, st);
+    else launch_frame_n<1536, false>(d, c, a, B, bf16, st);
+}
+#endif
 
 }  // namespace dn
 
-#ifdef DN_PROBE
+#if defined(DN_PROBE) && !defined(DN_HOP_TU_1536)
 // diagnostic build only: the stamps of the Griffin-Lim workgroup 0 of hop_kernel / frame_kernel
 extern "C" int dn_probe_read_hop(unsigned long long* host48) {
     return (int)hipMemcpyFromSymbol(host48, HIP_SYMBOL(dn::g_gl_probe), sizeof(dn::g_gl_probe));
