@@ -261,9 +261,14 @@ __global__ __launch_bounds__(kHopPipeThreads, FRONT ? kFrontPerCu : (NFFT == 153
     }
     // ---- ticket: the last workgroup of the launch advances the control block (every workgroup has read it by then)
     // Zero-copy host transport: the completion word the last workgroup publishes must not overtake ANY workgroup's samples.  A workgroup barrier
-    // orders LDS and (in this wave-sharing mode) does not have to wait for outstanding stores, and stores of different workgroups reach the host
-    // through different L2s: so every wave first waits until its own stores are acknowledged, and the ticket is a release / acquire pair at system
-    // scope -- each workgroup's samples happen-before its increment, every increment happens-before the last workgroup's publication.
+    // orders LDS and (in this wave-sharing mode) does not have to wait for outstanding stores: every wave therefore waits until its own stores are
+    // ACKNOWLEDGED (s_waitcnt vmcnt(0)) before the barrier that precedes its workgroup's ticket.  The samples go to page-locked host memory, which
+    // the L2s do not cache: an acknowledged store has left the chip's caches for the fabric, and the completion word -- written by the last
+    // workgroup after it has seen every ticket, behind a system-scope fence -- follows them through the same PCIe port, where posted writes of one
+    // device stay in order.  The strict form of the memory model -- the ticket as a release / acquire pair at SYSTEM scope -- is kept behind
+    // DN_HOST_STRICT_RELEASE: it writes an XCD's whole L2 back once per workgroup (the slots of the pipe are in there) and measured 10-14 % of the
+    // host-fed rate (256 streams 59.5 -> 68.0 us per hop, 1,024 streams 163.6 -> 186.5: profiles/r04_v4_side_measurements.jsonl) for stores that
+    // are not in the L2 in the first place.
     if (a.host_done != nullptr) DN_WAIT_VMEM();
     __syncthreads();
 #ifdef DN_PROBE
@@ -274,8 +279,12 @@ __global__ __launch_bounds__(kHopPipeThreads, FRONT ? kFrontPerCu : (NFFT == 153
     }
 #endif
     if (tid == 0) {
+#ifdef DN_HOST_STRICT_RELEASE
         const unsigned int t = a.host_done != nullptr ? __hip_atomic_fetch_add(&a.ctl->done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_SYSTEM)
                                                       : atomicAdd(&a.ctl->done, 1u);
+#else
+        const unsigned int t = atomicAdd(&a.ctl->done, 1u);
+#endif
         if (t == gridDim.x - 1) {
             a.ctl->done = 0;
             if (!FRONT) a.ctl->launches = launches + 1;     // (the chains' launch of a split hop has counted it: this one is launch `launches - 1` still)
