@@ -19,10 +19,13 @@
 //   advances, so one captured launch replays indefinitely under hipGraph (BASELINE config 5).
 #include "dn_hop_common.hpp"
 
-// The n_fft-1536 instantiations of the kernels below live in a translation unit of their own (dn_hop1536.hip includes this file with DN_HOP_TU_1536):
-// the n_fft-1024 kernels are compiled with LLVM's max-ILP scheduling strategy (Makefile: +1..3 % on the pipes, the unpipelined hop and the saturated
-// regime, profiles/r04_group_sweep.txt), which costs the 1536 ones 12 % (they sit at the 256-register cap and spill more under it).  The stamped
-// diagnostic build keeps everything in this file (its probe arrays are per translation unit).
+// The kernels below are instantiated in THREE translation units, because LLVM's GCN scheduling strategies suit them differently (Makefile; measured,
+// profiles/r04_group_sweep.txt):
+//   dn_hop.hip      (this file)  n_fft 1024, a wavefront per STFT column (the one-hop pipe, the unpipelined hop): max-ILP, +2..3 %;
+//   dn_hop_glw.hip  (DN_HOP_TU_GLW)   n_fft 1024, a wavefront per stream (deep pipes, the saturated regime, the front-only launch of a split hop):
+//                                     iterative-ILP, +3..7 % (1,024 streams 6.73 -> 7.00 M frames/s, the captured streaming step 6.34 -> 6.79 M);
+//   dn_hop1536.hip  (DN_HOP_TU_1536)  n_fft 1536: the default strategy (max-ILP costs it 12 %: it sits at the 256-register cap and spills more).
+// The stamped diagnostic build keeps everything in this file (its probe arrays are per translation unit).
 #if !defined(DN_PROBE)
 #define DN_HOP_SPLIT_TUS 1
 #endif
@@ -331,7 +334,7 @@ static void launch_hop_n(const DspDev& d, const CellDev& c, const HopArgs& a, bo
     }
 }
 
-#ifndef DN_HOP_TU_1536
+#if !defined(DN_HOP_TU_1536) && !defined(DN_HOP_TU_GLW)
 // a.glw: the caller laid the grid out for a wavefront per stream and chain segment (n_fft 1024 only) instead of a wavefront per column
 // The deferred host output of the LAST push (no further launch will carry it): copy, then publish (dn_pipe_stream_host_wait).
 __global__ void host_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, unsigned int n16) {
@@ -348,6 +351,7 @@ void launch_host_copy(const uint4* src, uint4* dst, unsigned int n16, unsigned l
 }
 
 void launch_hop_1536(const DspDev& d, const CellDev& c, const HopArgs& a, bool bf16, hipStream_t st);          // (dn_hop1536.hip)
+void launch_hop_glw(const DspDev& d, const CellDev& c, const HopArgs& a, bool bf16, hipStream_t st);           // (dn_hop_glw.hip)
 void launch_frame_1536(const DspDev& d, const CellDev& c, const FrameArgs& a, int B, bool bf16, hipStream_t st);
 
 void launch_hop(const DspDev& d, const CellDev& c, const HopArgs& a, bool bf16, hipStream_t st) {
@@ -370,8 +374,12 @@ void launch_hop(const DspDev& d, const CellDev& c, const HopArgs& a, bool bf16, 
         else launch_hop_n<1536, false, false>(d, c, a, bf16, st);
 #endif
     } else if (a.glw) {
+#ifdef DN_HOP_SPLIT_TUS
+        launch_hop_glw(d, c, a, bf16, st);
+#else
         if (stream) launch_hop_n<1024, true, true>(d, c, a, bf16, st);
         else launch_hop_n<1024, false, true>(d, c, a, bf16, st);
+#endif
     } else {
         if (stream) launch_hop_n<1024, true, false>(d, c, a, bf16, st);
         else launch_hop_n<1024, false, false>(d, c, a, bf16, st);
@@ -386,7 +394,7 @@ __global__ void ctl_set_kernel(PipeCtl* ctl, unsigned long long pushes, unsigned
 void launch_ctl_set(PipeCtl* ctl, unsigned long long pushes, unsigned long long frames, unsigned int pending, hipStream_t st) {
     hipLaunchKernelGGL(ctl_set_kernel, dim3(1), dim3(1), 0, st, ctl, pushes, frames, pending);
 }
-#endif          // DN_HOP_TU_1536
+#endif          // the n_fft-1024 per-column translation unit
 
 // ---- the unpipelined hop: P1-P12 of one stream in one workgroup, one launch per hop (zero added latency).  Four wavefronts for the
 // front half (the conv phases split four ways), three for the Griffin-Lim chain behind it (the fourth exits).
@@ -425,7 +433,7 @@ static void launch_frame_n(const DspDev& d, const CellDev& c, const FrameArgs& a
     }
 }
 
-#ifndef DN_HOP_TU_1536
+#if !defined(DN_HOP_TU_1536) && !defined(DN_HOP_TU_GLW)
 void launch_frame(const DspDev& d, const CellDev& c, const FrameArgs& a, int B, bool bf16, hipStream_t st) {
     const bool stream = a.ring != nullptr;
     if (d.n_fft == 1536) {
@@ -440,6 +448,11 @@ void launch_frame(const DspDev& d, const CellDev& c, const FrameArgs& a, int B, 
         else launch_frame_n<1024, false>(d, c, a, B, bf16, st);
     }
 }
+#elif defined(DN_HOP_TU_GLW)          // the wavefront-per-stream translation unit
+void launch_hop_glw(const DspDev& d, const CellDev& c, const HopArgs& a, bool bf16, hipStream_t st) {
+    if (a.ola != nullptr) launch_hop_n<1024, true, true>(d, c, a, bf16, st);
+    else launch_hop_n<1024, false, true>(d, c, a, bf16, st);
+}
 #else          // the n_fft-1536 translation unit
 void launch_hop_1536(const DspDev& d, const CellDev& c, const HopArgs& a, bool bf16, hipStream_t st) {
     if (a.ola != nullptr) launch_hop_n<1536, true, false>(d, c, a, bf16, st);
@@ -453,7 +466,7 @@ void launch_frame_1536(const DspDev& d, const CellDev& c, const FrameArgs& a, in
 
 }  // namespace dn
 
-#if defined(DN_PROBE) && !defined(DN_HOP_TU_1536)
+#if defined(DN_PROBE) && !defined(DN_HOP_TU_1536) && !defined(DN_HOP_TU_GLW)
 // diagnostic build only: the stamps of the Griffin-Lim workgroup 0 of hop_kernel / frame_kernel
 extern "C" int dn_probe_read_hop(unsigned long long* host48) {
     return (int)hipMemcpyFromSymbol(host48, HIP_SYMBOL(dn::g_gl_probe), sizeof(dn::g_gl_probe));
