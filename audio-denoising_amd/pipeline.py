@@ -652,11 +652,11 @@ def throughput_plan(batch: int, n_fft: int = 1024) -> dict:
     ``QueuedHopPipelines``.  Every choice gives the same samples; what changes is how many hops lie between handing a hop over and its output.
     ``group`` > 0: input that can be handed over ``group`` hops at a time goes through hop groups (``submit_group``: whole Griffin-Lim chains
     per launch, nothing parked); ``depth`` is what a caller that submits hop by hop gets instead.
-      up to 384 streams    one pipe; groups of four hops (batch 256: 38.9 us per hop) -- hop by hop: four hops in flight (45.8 us; 56.1 at depth 1)
-      385 .. 1,023         one pipe; groups of two hops, two streams a chain workgroup (512 streams: 6.5 M frames/s) -- hop by hop: depth 2 (6.1 M)
-      1,024 .. 2,047       two pipes on two HIP streams, split hops, two hops in flight (1,024 streams: 7.6 M frames/s against 6.7 M)
+      up to 384 streams    one pipe; groups of four hops (batch 256: 36.9 us per hop) -- hop by hop: four hops in flight (45.9 us; 54.7 at depth 1)
+      385 .. 1,023         one pipe; groups of two hops, two streams a chain workgroup (512 streams: 6.9 M frames/s) -- hop by hop: depth 2 (6.4 M)
+      1,024 .. 2,047       two pipes on two HIP streams, split hops, two hops in flight (1,024 streams: 8.0 M frames/s against 6.9 M)
       2,048 and up         an even number of pipes of about 1,024 streams, taking turns on two HIP streams, split hops, one hop in flight
-                           (2,048 / 4,096 / 8,192 streams: 8.0 M frames/s against 7.0 / 7.3 / 7.6 M for one pipe)
+                           (2,048 / 4,096 / 8,192 streams: 8.4 M frames/s against 7.2 / 7.4 / 7.7 M for one pipe)
     n_fft 1536 (the wavefront-per-stream schedule is not built there): one pipe at depth 1."""
     if n_fft != 1024:
         return {"queues": 1, "pipes": 1, "depth": 1, "split": False, "group": 0}
